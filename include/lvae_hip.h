@@ -1,0 +1,227 @@
+/*
+ * liblvae_hip.so — C ABI of the MI355X (gfx950) Ladder-VAE hot path.
+ *
+ * The reference (addtt/ladder-vae-pytorch) has no FFI/plugin boundary of its own: its hot path is stock torch
+ * ops called from Python. Each entry point below therefore names the reference call site(s)
+ * whose arithmetic it replaces (paths relative to the reference root), and INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - activations are NHWC, contiguous, float32, device memory; `N` = batch.
+ *  - the caller owns every buffer including workspaces; nothing here allocates, synchronises or touches the
+ *    default stream. `stream` is a hipStream_t passed as void*.
+ *  - every function returns 0 on success, a negative LVAE_E* code for a rejected argument, or the positive
+ *    hipError_t of a failed launch. `lvae_last_error()` returns a static description of the last failure.
+ *  - re-entrant; no mutable global state except the last-error string (thread-local).
+ */
+#ifndef LVAE_HIP_H
+#define LVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVAE_ABI_VERSION 1
+
+#define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
+#define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
+#define LVAE_EWORKSPACE (-3) /* workspace too small */
+
+/* activation ids shared by every kernel (models/lvae.py:64-69 nonlin table) */
+enum { LVAE_ACT_NONE = 0, LVAE_ACT_ELU = 1, LVAE_ACT_RELU = 2, LVAE_ACT_LEAKYRELU = 3, LVAE_ACT_SELU = 4 };
+
+/* spatial gather of an implicit-GEMM convolution */
+enum {
+  LVAE_GATHER_CONV = 0,      /* ih = oh*stride - pad + kh           (nn.Conv2d forward; dgrad of ConvTranspose2d) */
+  LVAE_GATHER_TRANSPOSED = 1 /* ih = (oh + pad - kh)/stride if exact (nn.ConvTranspose2d forward; dgrad of Conv2d) */
+};
+
+int lvae_abi_version(void);
+const char* lvae_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ *
+ *   y[n,oh,ow,co] = out_act( (bias[co] + sum_{kh,kw,ci} T(x)[n,ih,iw,ci] * w[kh,kw,ci,co]) * out_scale[n,co] )
+ *   T(x)[..ci] = in_act(x[..ci]*in_scale[ci] + in_shift[ci])   (identity when in_scale == NULL), zero outside the image
+ *
+ * replaces: nn.Conv2d / nn.ConvTranspose2d call sites lib/nn.py:83-87,118 ; lib/stochastic.py:25-27 ;
+ *           models/lvae.py:73-76 ; models/lvae_layers.py:263-276,347-356 ; lib/likelihoods.py:55-58,199-202
+ *           with the BatchNorm-apply + activation of lib/nn.py:80-82 fused into T, the Dropout2d scaling of
+ *           lib/nn.py:89 fused into out_scale, torch.cat of models/lvae_layers.py:359 fused as (x, x2), and the
+ *           autograd dgrad of all of them (same kernel, transposed weight strides, other gather).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct lvae_conv_desc {
+  const float* x;        /* [N,H,W,C1] */
+  const float* x2;       /* [N,H,W,C2] or NULL: channels C1..C1+C2 of the logical input */
+  int32_t C1, C2;
+  const float* w;        /* element (tap, k, n) at w[tap*w_stap + k*w_sk + n*w_sn]; k = GEMM reduction channel */
+  int64_t w_stap, w_sk, w_sn;
+  const float* bias;     /* [Cout] or NULL */
+  const float* in_scale; /* [C1+C2] or NULL */
+  const float* in_shift; /* [C1+C2] (required when in_scale != NULL) */
+  int32_t in_act;
+  const float* out_scale; /* [N,Cout] or NULL */
+  int32_t out_act;
+  float* y;              /* [N,OH,OW,Cout] */
+  int32_t N, H, W, OH, OW, Cout;
+  int32_t KH, KW, stride, pad;
+  int32_t gather;        /* LVAE_GATHER_* */
+} lvae_conv_desc;
+
+int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+
+/* Weight / bias gradient of the convolution described by `d` (d->y is unused, d->w gives only the strides):
+ *   dw[tap,k,n] += sum_{n,oh,ow} T(x)[n,ih,iw,k] * dy[n,oh,ow,n]     db[n] += sum dy[..,n]
+ * written with the strides d->w_stap/w_sk/w_sn into `dw` (accumulating). Deterministic: split-K partial slabs
+ * in `workspace` are summed in a fixed order by a second kernel. `dy` is [N,OH,OW,Cout].
+ * workspace bytes needed: lvae_conv2d_wgrad_workspace(d).
+ * replaces: autograd's convolution_backward (weight, bias) for every call site listed above. */
+size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d);
+int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d (training statistics) — lib/nn.py:80-81 (nn.BatchNorm2d, momentum 0.1, eps 1e-5)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Per-channel batch statistics of x [M,C] (M = N*H*W): writes
+ *   scale[c] = gamma[c]*rstd[c], shift[c] = beta[c] - mean[c]*scale[c], mean[c], rstd[c]
+ * and, when running_mean != NULL, updates running_mean/var with `momentum` (unbiased variance).
+ * workspace: lvae_bn_stats_workspace(M, C) bytes. */
+size_t lvae_bn_stats_workspace(int64_t M, int32_t C);
+int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                      float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+/* Inference form: scale/shift from the running statistics. */
+int lvae_bn_eval_coeffs_f32(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale, float* shift, void* stream);
+
+/* y = act(x*scale[c] + shift[c]) materialised (used where no convolution consumes it: 'cabdcabd' blocks). */
+int lvae_affine_act_f32(const float* x, int64_t M, int32_t C, const float* scale, const float* shift, int32_t act,
+                        const float* row_scale, int64_t rows_per_n, float* y, void* stream);
+
+/* Backward of h = act(x*scale + shift) with batch statistics (BatchNorm training) or fixed coefficients.
+ *   g = dh * act'(u), u = x*scale+shift
+ *   bn_train: dgamma += sum g*xhat, dbeta += sum g, dx = scale*(g - mean(g) - xhat*mean(g*xhat))
+ *   else    : dx = scale*g
+ * then dx *= drop[n,c] (optional Dropout2d mask of the producer) and dx += add (optional residual gradient).
+ * Two launches (reduce, apply); workspace lvae_bn_stats_workspace(M,C) bytes. */
+int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t M, int32_t C, const float* scale,
+                            const float* shift, int32_t act, int32_t bn_train, const float* mean, const float* rstd,
+                            float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n, const float* add,
+                            float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GateLayer2d epilogue + residual add — lib/nn.py:121-126 and lib/nn.py:99
+ *   ab [M,2C] -> out[m,c] = act(ab[m,c]) * sigmoid(ab[m,C+c]) + res[m,c]      (res may be NULL)
+ *   bwd: dab[m,c] = dout*sigmoid(b)*act'(a) ; dab[m,C+c] = dout*act(a)*sigmoid(b)*(1-sigmoid(b))
+ * ---------------------------------------------------------------------------------------------------------- */
+int lvae_gate_fwd_f32(const float* ab, const float* res, int64_t M, int32_t C, int32_t act, float* out, void* stream);
+int lvae_gate_bwd_f32(const float* dout, const float* ab, int64_t M, int32_t C, int32_t act, float* dab, void* stream);
+
+/* generic small elementwise helpers used by the host glue */
+/* y = act(x) in place-capable; dact: dx = dy * act'(x) expressed from the OUTPUT y (elu/relu/leaky/selu allow it) */
+int lvae_act_bwd_from_out_f32(const float* dy, const float* y, int64_t n, int32_t act, float* dx, void* stream);
+int lvae_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* residual without gate (lib/nn.py:99 when gated is falsy): out = (a*rowscale) + b */
+int lvae_scale_rows_add_f32(const float* a, const float* row_scale, int64_t rows_per_n, int32_t C, const float* b,
+                            int64_t M, float* out, void* stream);
+/* out[p] (+)= sum_r x[r, p]  (batch reduction of a broadcast parameter's gradient, e.g. top_prior_params) */
+int lvae_colsum_f32(const float* x, int64_t R, int64_t P, float* out, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * NormalStochasticBlock2d elementwise core — lib/stochastic.py:45-99 and kl_normal_mc lib/stochastic.py:209-226
+ * p, q: [N,HW,2Z] (mu = channels [0,Z), logvar = [Z,2Z)); p may be batch-broadcast (p_bcast=1: [1,HW,2Z]); q may be
+ * NULL (sample from p). mode: 0 = z = mu + exp(lv/2)*eps, 1 = z = mu (use_mode), 2 = z given (forced_latent).
+ * outputs: z [N,HW,Z]; logprob_p, logprob_q, kl_samplewise [N]; kl_spatial [N,HW] (analytical, sum over Z).
+ * ---------------------------------------------------------------------------------------------------------- */
+int lvae_normal_stochastic_fwd_f32(const float* p, int32_t p_bcast, const float* q, const float* eps, int32_t N,
+                                   int32_t HW, int32_t Z, int32_t mode, int32_t analytical_kl, float* z,
+                                   float* logprob_p, float* logprob_q, float* kl_samplewise, float* kl_spatial,
+                                   void* stream);
+/* Backward. Upstream: dz [N,HW,Z] (may be NULL), g_lp, g_lq, g_kl [N] (may be NULL), g_ks [N,HW] (may be NULL).
+ * Writes dp [N,HW,2Z] (caller sums over N when p was broadcast) and dq [N,HW,2Z] (NULL when q is NULL). */
+int lvae_normal_stochastic_bwd_f32(const float* p, int32_t p_bcast, const float* q, const float* eps, const float* z,
+                                   const float* dz, const float* g_lp, const float* g_lq, const float* g_kl,
+                                   const float* g_ks, int32_t N, int32_t HW, int32_t Z, int32_t mode,
+                                   int32_t analytical_kl, float* dp, float* dq, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Likelihood heads (elementwise part; the 3x3 parameter conv is lvae_conv2d_f32)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Bernoulli — lib/likelihoods.py:60-78,385-388. logits [N,P] (P = H*W*C), x [N,P] or NULL, u [N,P] uniforms.
+ * mean = sigmoid(logits), mode = round(mean), sample = u < mean, ll[n] = sum x*max(log m,-100)+(1-x)*max(log(1-m),-100)
+ * dll_dlogits [N,P] (optional) = d ll[n] / d logits. */
+int lvae_bernoulli_fwd_f32(const float* logits, const float* x, const float* u, int32_t N, int64_t P, float* mean,
+                           float* mode, float* sample, float* ll, float* dll_dlogits, void* stream);
+/* Discretized mixture of logistics — lib/likelihoods.py:291-382 (x given in [0,1]; the 2x-1 of :228 is applied here).
+ * l [N,HW,10*nmix], x [N,HW,3]; ll [N]; dll_dl [N,HW,10*nmix] optional. */
+size_t lvae_dmol_workspace(int32_t N, int32_t HW);
+int lvae_dmol_ll_fwd_f32(const float* l, const float* x, int32_t N, int32_t HW, int32_t nmix, float* ll, float* dll_dl,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* lib/stochastic.py:141-206 + the (s+1)/2 clamp of lib/likelihoods.py:221-225.
+ * u_mix [N,HW,nmix], u_log [N,HW,3] uniforms in (1e-5, 1-1e-5); sample [N,HW,3] in [0,1]. */
+int lvae_dmol_sample_f32(const float* l, const float* u_mix, const float* u_log, int32_t N, int32_t HW, int32_t nmix,
+                         float* sample, void* stream);
+/* out[n, i] = g[n] * a[n, i]  (chain rule through a per-sample scalar; backward of the two heads above) */
+int lvae_scale_per_sample_f32(const float* a, const float* g, int32_t N, int64_t P, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Resampling / geometry
+ * ---------------------------------------------------------------------------------------------------------- */
+/* bilinear x2, align_corners=False — boilr.nn.Interpolate(scale=2) at models/lvae.py:143-144 (restated, unpinned) */
+int lvae_upsample2x_fwd_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
+int lvae_upsample2x_bwd_f32(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
+/* centred zero pad (OH>=H) or centre crop (OH<=H) — boilr pad_img_tensor / crop_img_tensor, models/lvae.py:185,324.
+ * Also converts layout: src_nchw / dst_nchw select NCHW vs NHWC on either side. */
+int lvae_pad_crop_f32(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_nchw, float* y, int32_t OH,
+                      int32_t OW, int32_t dst_nchw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KL bookkeeping + free bits — models/lvae.py:192-198 with boilr.nn.free_bits_kl (restated, parity unpinned):
+ *   kl [L,N] (layer-major) -> kl_sep[n] = sum_l, kl_avg_layerwise[l] = mean_n,
+ *   scalars[0] = kl_loss = sum_l mean_n max(kl, free_bits)   (plain mean when free_bits < 1e-6)
+ *   scalars[1] = kl      = mean_n kl_sep
+ * bwd: dkl from upstream g_sep [N], g_avg [L], g_scalars [2] (each may be NULL).
+ * ---------------------------------------------------------------------------------------------------------- */
+int lvae_kl_bookkeeping_fwd_f32(const float* kl, int32_t L, int32_t N, float free_bits, float* kl_sep,
+                                float* kl_avg_layerwise, float* scalars, void* stream);
+int lvae_kl_bookkeeping_bwd_f32(const float* kl, int32_t L, int32_t N, float free_bits, const float* g_sep,
+                                const float* g_avg, const float* g_scalars, float* dkl, void* stream);
+/* ELBO / loss assembly — experiment/experiment_manager.py:329-344:
+ *   elbo_sep[n] = ll[n] - kl_sep[n]; scalars[0] = loss = mean(-ll) + beta*kl_loss; [1] = elbo; [2] = recons
+ * bwd (of `loss` only; elbo/recons are metrics): d_ll[n] = -g/N, d_kl_loss = g*beta, g = g_loss[0] on device. */
+int lvae_elbo_loss_fwd_f32(const float* ll, const float* kl_sep, const float* kl_loss, float beta, int32_t N,
+                           float* elbo_sep, float* scalars, void* stream);
+int lvae_elbo_loss_bwd_f32(const float* g_loss, float beta, int32_t N, float* d_ll, float* d_kl_loss, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser and norms over the flat parameter arena — torch.optim.Adamax at experiment_manager.py:76-81 and the
+ * L2 loop at experiment_manager.py:346-350.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* step_count: device uint64[1] holding the number of COMPLETED steps (advance it with lvae_counter_advance after the
+ * update; both are plain launches, so a captured graph replays them). mask [n] (optional, 0/1): elements with 0 are frozen (parameters that do not require grad). gscale: device float
+ * pointer (optional) multiplied into the gradient (1/world_size after a sum all-reduce). */
+int lvae_adamax_step_f32(float* p, const float* g, float* exp_avg, float* exp_inf, const float* mask, int64_t n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, const float* gscale,
+                         const uint64_t* step_count, void* stream);
+/* out[0] = sqrt(sum x^2) ; workspace >= lvae_sumsq_workspace(n) bytes; deterministic two-pass */
+size_t lvae_sumsq_workspace(int64_t n);
+int lvae_l2norm_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * On-device noise (Philox4x32-10). `seed` is a host value; `offset` a device uint64[1] step counter advanced
+ * with lvae_counter_advance (a plain launch, so graph replays draw fresh numbers); `stream_id` names the call site.
+ * kind: 0 = standard normal, 1 = uniform(lo,hi), 2 = Bernoulli(p=lo) keep-mask scaled by `hi` (Dropout2d: hi=1/(1-p))
+ * ---------------------------------------------------------------------------------------------------------- */
+int lvae_rng_fill_f32(float* out, int64_t n, int32_t kind, float lo, float hi, uint64_t seed, const uint64_t* offset,
+                      uint64_t stream_id, void* stream);
+int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVAE_HIP_H */

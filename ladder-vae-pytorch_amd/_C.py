@@ -1,0 +1,118 @@
+"""ctypes binding of liblvae_hip.so (the C ABI declared in include/lvae_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call is made without a GPU tensor the
+import / call raises. PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
+
+ACT = {None: 0, 'none': 0, 'elu': 1, 'relu': 2, 'leakyrelu': 3, 'selu': 4}
+GATHER_CONV, GATHER_TRANSPOSED = 0, 1
+
+
+class LvaeHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of struct lvae_conv_desc"""
+    _fields_ = [
+        ('x', C.c_void_p), ('x2', C.c_void_p), ('C1', C.c_int32), ('C2', C.c_int32),
+        ('w', C.c_void_p), ('w_stap', C.c_int64), ('w_sk', C.c_int64), ('w_sn', C.c_int64),
+        ('bias', C.c_void_p), ('in_scale', C.c_void_p), ('in_shift', C.c_void_p), ('in_act', C.c_int32),
+        ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
+        ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
+        ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+        ('gather', C.c_int32),
+    ]
+
+
+_P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); every symbol of include/lvae_hip.h
+SIGNATURES = {
+    'lvae_abi_version': (C.c_int, []),
+    'lvae_last_error': (C.c_char_p, []),
+    'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
+    'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    'lvae_bn_stats_workspace': (_Z, [_L, _I]),
+    'lvae_bn_stats_f32': (C.c_int, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'lvae_bn_eval_coeffs_f32': (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    'lvae_affine_act_f32': (C.c_int, [_P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
+    'lvae_affine_act_bwd_f32': (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
+    'lvae_gate_fwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
+    'lvae_gate_bwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
+    'lvae_act_bwd_from_out_f32': (C.c_int, [_P, _P, _L, _I, _P, _P]),
+    'lvae_add_f32': (C.c_int, [_P, _P, _L, _P, _P]),
+    'lvae_scale_rows_add_f32': (C.c_int, [_P, _P, _L, _I, _P, _L, _P, _P]),
+    'lvae_colsum_f32': (C.c_int, [_P, _L, _L, _P, _I, _P]),
+    'lvae_normal_stochastic_fwd_f32': (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'lvae_normal_stochastic_bwd_f32': (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lvae_bernoulli_fwd_f32': (C.c_int, [_P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
+    'lvae_dmol_workspace': (_Z, [_I, _I]),
+    'lvae_dmol_ll_fwd_f32': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    'lvae_dmol_sample_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'lvae_scale_per_sample_f32': (C.c_int, [_P, _P, _I, _L, _P, _P]),
+    'lvae_upsample2x_fwd_f32': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    'lvae_upsample2x_bwd_f32': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    'lvae_pad_crop_f32': (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    'lvae_kl_bookkeeping_fwd_f32': (C.c_int, [_P, _I, _I, _F, _P, _P, _P, _P]),
+    'lvae_kl_bookkeeping_bwd_f32': (C.c_int, [_P, _I, _I, _F, _P, _P, _P, _P, _P]),
+    'lvae_elbo_loss_fwd_f32': (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P]),
+    'lvae_elbo_loss_bwd_f32': (C.c_int, [_P, _F, _I, _P, _P, _P]),
+    'lvae_adamax_step_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P]),
+    'lvae_sumsq_workspace': (_Z, [_L]),
+    'lvae_l2norm_f32': (C.c_int, [_P, _L, _P, _P, _Z, _P]),
+    'lvae_rng_fill_f32': (C.c_int, [_P, _L, _I, _F, _F, _U, _P, _U, _P]),
+    'lvae_counter_advance': (C.c_int, [_P, _U, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen liblvae_hip.so and type every entry point. Raises LvaeHipError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LvaeHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                           "`make -C ladder-vae-pytorch_amd/csrc`. There is no CPU / PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.lvae_abi_version() != 1:
+        raise LvaeHipError("liblvae_hip.so ABI version %d, expected 1" % lib.lvae_abi_version())
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL). Refuses CPU tensors: the HIP path never runs on host memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LvaeHipError("lvae_hip kernels need CUDA/HIP tensors; got a %s tensor (no CPU fallback exists)" % t.device)
+    if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.uint8:
+        raise LvaeHipError("unexpected dtype %s" % t.dtype)
+    return t.data_ptr()
+
+
+def check(rc, name):
+    if rc != 0:
+        raise LvaeHipError("%s failed (%d): %s" % (name, rc, load().lvae_last_error().decode()))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,307 @@
+// Weight / bias gradient of the implicit-GEMM convolution on fp32 MFMA.
+//
+//   dW[tap][ci][co] = sum_{m=(n,oh,ow)} T(x)[m @ tap][ci] * dy[m][co]        db[co] = sum_m dy[m][co]
+//
+// GEMM view per tap: M' = ci (A = T(x)^T), N' = co (B = dy), K' = output pixels. Both operands are pixel-major
+// in memory (NHWC), i.e. already "k-major": the LDS stages are [pixel][channel] and the MFMA fragments are
+// ds_read_b32 of 32 consecutive channels (conflict free). The pixel range is split over `ksplit` workgroups
+// per (tap, ci-tile, co-tile); each writes its 64x64 partial to a slab, and a second kernel sums the slabs in a
+// fixed order (bitwise reproducible, no float atomics) and accumulates into the gradient arena.
+#include "lvae_common.h"
+
+namespace lvae {
+
+int conv_desc_check(const lvae_conv_desc* d, const char* who);
+
+constexpr int KP = 32;   // pixels per stage
+constexpr int CT = 64;   // channel tile (both ci and co)
+
+struct WgradArgs {
+  lvae_conv_desc d;
+  const float* dy;
+  float* slab_w;   // [ksplit][taps][Cin][Cout]
+  float* slab_b;   // [ksplit][Cout]
+  int M, ohw, Cin, ntaps, ncit, ncot, ksplit, px_per_split;
+};
+
+__device__ __forceinline__ bool tap_coord_w(int o, int k, int stride, int pad, int limit, int gather, int& i) {
+  if (gather == LVAE_GATHER_CONV) {
+    i = o * stride - pad + k;
+    return i >= 0 && i < limit;
+  }
+  int t = o + pad - k;
+  if (t < 0) return false;
+  i = t / stride;
+  return (t - i * stride == 0) && i < limit;
+}
+
+template <bool X_VEC, bool Y_VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][KP][CT];
+  __shared__ __attribute__((aligned(16))) float Ys[2][KP][CT];
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+
+  int bid = blockIdx.x;
+  const int ks = bid % a.ksplit;
+  bid /= a.ksplit;
+  const int cot = bid % a.ncot;
+  bid /= a.ncot;
+  const int cit = bid % a.ncit;
+  const int tap = bid / a.ncit;
+  const int kh = tap / d.KW, kw = tap - kh * d.KW;
+  const int ci0 = cit * CT, co0 = cot * CT;
+  const int p_begin = ks * a.px_per_split;
+  const int p_end = min(a.M, p_begin + a.px_per_split);
+  const bool do_bias = (a.slab_b != nullptr) && tap == 0 && cit == 0;
+
+  // vector staging: thread -> pixel row (t>>4) + 16*p, channels (t&15)*4
+  const int prow = t >> 4, c4 = (t & 15) * 4;
+  f32x4 xr[2], yr[2];
+  float xs_[8], ys_[8];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  float bsum_s = 0.f;
+
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  float sc_s = 1.f, sh_s = 0.f;
+  if (X_VEC) {
+    if (d.in_scale && ci0 + c4 < a.Cin) {
+      sc = *reinterpret_cast<const f32x4*>(d.in_scale + ci0 + c4);
+      sh = *reinterpret_cast<const f32x4*>(d.in_shift + ci0 + c4);
+    }
+  } else if (d.in_scale && ci0 + (t & 63) < a.Cin) {
+    sc_s = d.in_scale[ci0 + (t & 63)];
+    sh_s = d.in_shift[ci0 + (t & 63)];
+  }
+
+  auto load_x_pixel = [&](int m, int& n, int& ih, int& iw) -> bool {
+    if (m >= p_end) return false;
+    n = m / a.ohw;
+    int rem = m - n * a.ohw;
+    int oh = rem / d.OW, ow = rem - oh * d.OW;
+    return tap_coord_w(oh, kh, d.stride, d.pad, d.H, d.gather, ih) &&
+           tap_coord_w(ow, kw, d.stride, d.pad, d.W, d.gather, iw);
+  };
+
+  auto load_stage = [&](int p0) {
+    if (X_VEC) {
+      const int ci = ci0 + c4;
+      const float* src = d.x;
+      int cs = ci, cstride = d.C1;
+      if (ci >= d.C1) {
+        src = d.x2;
+        cs = ci - d.C1;
+        cstride = d.C2;
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int n, ih, iw;
+        if (ci < a.Cin && load_x_pixel(p0 + prow + 16 * p, n, ih, iw)) {
+          v = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * d.H + ih) * d.W + iw) * cstride + cs);
+          if (d.in_scale) {
+            v = v * sc + sh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.in_act);
+          }
+        }
+        xr[p] = v;
+      }
+    } else {
+      const int ci = ci0 + (t & 63);
+      const float* src = d.x;
+      int cs = ci, cstride = d.C1;
+      if (ci >= d.C1) {
+        src = d.x2;
+        cs = ci - d.C1;
+        cstride = d.C2;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+        int n, ih, iw;
+        if (ci < a.Cin && load_x_pixel(p0 + (t >> 6) + 4 * e, n, ih, iw)) {
+          v = src[((size_t)(n * d.H + ih) * d.W + iw) * cstride + cs];
+          if (d.in_scale) v = act_fwd(v * sc_s + sh_s, d.in_act);
+        }
+        xs_[e] = v;
+      }
+    }
+    if (Y_VEC) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int m = p0 + prow + 16 * p;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p_end && co0 + c4 < d.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * d.Cout + co0 + c4);
+        yr[p] = v;
+        if (do_bias) bsum += v;
+      }
+    } else {
+      const int co = co0 + (t & 63);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = p0 + (t >> 6) + 4 * e;
+        float v = (m < p_end && co < d.Cout) ? a.dy[(size_t)m * d.Cout + co] : 0.f;
+        ys_[e] = v;
+        if (do_bias) bsum_s += v;
+      }
+    }
+  };
+
+  auto store_stage = [&](int buf) {
+    if (X_VEC) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&Xs[buf][prow + 16 * p][c4]) = xr[p];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Xs[buf][(t >> 6) + 4 * e][t & 63] = xs_[e];
+    }
+    if (Y_VEC) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&Ys[buf][prow + 16 * p][c4]) = yr[p];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Ys[buf][(t >> 6) + 4 * e][t & 63] = ys_[e];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int nstages = (p_end - p_begin + KP - 1) / KP;
+  if (nstages > 0) {
+    load_stage(p_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstages) load_stage(p_begin + (s + 1) * KP);
+    const float* xa = &Xs[buf][lh][wci * 32 + li];
+    const float* yb = &Ys[buf][lh][wco * 32 + li];
+#pragma unroll
+    for (int kk = 0; kk < KP; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk * CT], yb[kk * CT], acc, 0, 0, 0);
+    if (s + 1 < nstages) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab [ks][tap][Cin][Cout]; C/D layout: col = lane&31 (co), row = (r&3)+8*(r>>2)+4*lh (ci)
+  float* slab = a.slab_w + ((size_t)ks * a.ntaps + tap) * a.Cin * d.Cout;
+  const int co = co0 + wco * 32 + li;
+  if (co < d.Cout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ci < a.Cin) slab[(size_t)ci * d.Cout + co] = acc[r];
+    }
+  }
+
+  if (do_bias) {
+    // reduce the per-thread column sums over the pixel rows of the block through LDS (reuse Ys[0])
+    __syncthreads();
+    float* red = &Ys[0][0][0];
+    if (Y_VEC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[prow * CT + c4 + j] = bsum[j];
+      __syncthreads();
+      if (t < CT) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * CT + t];
+        if (co0 + t < d.Cout) a.slab_b[(size_t)ks * d.Cout + co0 + t] = s;
+      }
+    } else {
+      red[(t >> 6) * CT + (t & 63)] = bsum_s;
+      __syncthreads();
+      if (t < CT) {
+        float s = red[t] + red[CT + t] + red[2 * CT + t] + red[3 * CT + t];
+        if (co0 + t < d.Cout) a.slab_b[(size_t)ks * d.Cout + co0 + t] = s;
+      }
+    }
+  }
+}
+
+// dw[tap*stap + ci*sk + co*sn] += sum_ks slab[ks][tap][ci][co] ;  db[co] += sum_ks slab_b[ks][co]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab_w, const float* slab_b, int ksplit,
+                                                            int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
+                                                            int64_t sn, float* dw, float* db) {
+  const int per = ntaps * Cin * Cout;
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < per) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += slab_w[(size_t)k * per + idx];
+    const int co = idx % Cout, r = idx / Cout, ci = r % Cin, tap = r / Cin;
+    dw[tap * stap + ci * sk + co * sn] += s;
+  } else if (db && idx < per + Cout) {
+    const int co = idx - per;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += slab_b[(size_t)k * Cout + co];
+    db[co] += s;
+  }
+}
+
+static void wgrad_plan(const lvae_conv_desc* d, int& ksplit, int& px_per_split, int& ncit, int& ncot) {
+  const int Cin = d->C1 + d->C2, M = d->N * d->OH * d->OW, ntaps = d->KH * d->KW;
+  ncit = (Cin + CT - 1) / CT;
+  ncot = (d->Cout + CT - 1) / CT;
+  const int tiles = ntaps * ncit * ncot;
+  int want = (512 + tiles - 1) / tiles;           // ~2 workgroups per CU in total
+  int maxsplit = (M + 255) / 256;                 // at least 8 stages per workgroup
+  ksplit = want < 1 ? 1 : want;
+  if (ksplit > maxsplit) ksplit = maxsplit;
+  if (ksplit < 1) ksplit = 1;
+  px_per_split = (M + ksplit - 1) / ksplit;
+  px_per_split = (px_per_split + KP - 1) / KP * KP;
+  ksplit = (M + px_per_split - 1) / px_per_split;
+}
+
+}  // namespace lvae
+
+using namespace lvae;
+
+extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
+  if (!d) return 0;
+  int ksplit, pps, ncit, ncot;
+  wgrad_plan(d, ksplit, pps, ncit, ncot);
+  const size_t per = (size_t)d->KH * d->KW * (d->C1 + d->C2) * d->Cout + d->Cout;
+  return (size_t)ksplit * per * sizeof(float);
+}
+
+extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = conv_desc_check(d, "lvae_conv2d_wgrad_f32");
+  if (rc) return rc;
+  LVAE_REQUIRE(dy && dw && workspace, LVAE_EINVAL, "lvae_conv2d_wgrad_f32: null dy/dw/workspace");
+  LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
+               "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
+  WgradArgs a;
+  a.d = *d;
+  a.dy = dy;
+  a.M = d->N * d->OH * d->OW;
+  a.ohw = d->OH * d->OW;
+  a.Cin = d->C1 + d->C2;
+  a.ntaps = d->KH * d->KW;
+  wgrad_plan(d, a.ksplit, a.px_per_split, a.ncit, a.ncot);
+  a.slab_w = static_cast<float*>(workspace);
+  a.slab_b = db ? a.slab_w + (size_t)a.ksplit * a.ntaps * a.Cin * d->Cout : nullptr;
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool xv = (d->C1 % 4 == 0) && (d->C2 % 4 == 0) && al(d->x) && (!d->x2 || al(d->x2)) &&
+                  (!d->in_scale || (al(d->in_scale) && al(d->in_shift)));
+  const bool yv = (d->Cout % 4 == 0) && al(dy);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = a.ksplit * a.ncot * a.ncit * a.ntaps;
+  if (xv && yv) hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+  else if (xv) hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), dim3(grid), dim3(256), 0, s, a);
+  else if (yv) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+  LVAE_LAUNCH_CHECK("conv2d_wgrad");
+  const int per = a.ntaps * a.Cin * d->Cout + (db ? d->Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, a.slab_w, a.slab_b, a.ksplit,
+                     a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
+  LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
+  return 0;
+}

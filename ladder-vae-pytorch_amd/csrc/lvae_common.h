@@ -1,0 +1,95 @@
+// Shared device helpers for liblvae_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lvae_hip.h"
+
+namespace lvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void set_error(const char* fmt, ...);
+
+#define LVAE_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      lvae::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define LVAE_LAUNCH_CHECK(name)                                        \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) {                                           \
+      lvae::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return (int)e__;                                                 \
+    }                                                                  \
+  } while (0)
+
+constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
+constexpr float kSeluScale = 1.0507009873554804934193349852946f;
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case LVAE_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case LVAE_ACT_RELU: return x > 0.f ? x : 0.f;
+    case LVAE_ACT_LEAKYRELU: return x > 0.f ? x : 0.01f * x;
+    case LVAE_ACT_SELU: return kSeluScale * (x > 0.f ? x : kSeluAlpha * expm1f(x));
+    default: return x;
+  }
+}
+
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case LVAE_ACT_ELU: return x > 0.f ? 1.f : __expf(x);
+    case LVAE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case LVAE_ACT_LEAKYRELU: return x > 0.f ? 1.f : 0.01f;
+    case LVAE_ACT_SELU: return kSeluScale * (x > 0.f ? 1.f : kSeluAlpha * __expf(x));
+    default: return 1.f;
+  }
+}
+
+// derivative expressed from the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  switch (act) {
+    case LVAE_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+    case LVAE_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case LVAE_ACT_LEAKYRELU: return y > 0.f ? 1.f : 0.01f;
+    case LVAE_ACT_SELU: return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// numerically stable softplus, threshold 20 like torch
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over a 256-thread block; result valid in every thread. `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 8) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace lvae

@@ -1,0 +1,521 @@
+// BatchNorm statistics, fused affine+activation forward/backward, GateLayer2d epilogue, small elementwise glue.
+// All HBM-bound: NHWC rows of C channels are read as float4 per lane (C % 4 == 0) with consecutive lanes on
+// consecutive channels/rows, per-channel reductions go through registers -> LDS -> per-chunk partials and a
+// fixed-order finalize (no float atomics: bitwise reproducible).
+#include "lvae_common.h"
+
+namespace lvae {
+
+constexpr int kMaxChunks = 512;
+
+struct RowMap {
+  int cols;   // float4 (or scalar) columns per row handled by distinct threads
+  int rpp;    // rows per pass of a 256-thread block
+};
+
+static inline RowMap row_map(int C, int vec) {
+  RowMap r;
+  r.cols = C / vec;
+  r.rpp = 256 / r.cols;
+  return r;
+}
+
+static inline int chunk_count(int64_t M, int rpp) {
+  int64_t want = (M + (int64_t)rpp * 8 - 1) / ((int64_t)rpp * 8);
+  if (want < 1) want = 1;
+  if (want > kMaxChunks) want = kMaxChunks;
+  return (int)want;
+}
+
+template <int V>
+struct Vec;
+struct alignas(16) F4 {
+  float v[4];
+};
+template <>
+struct Vec<4> {
+  typedef F4 T;
+  static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const F4*>(p); }
+  static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<F4*>(p) = v; }
+};
+template <>
+struct Vec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+};
+template <int V>
+__device__ __forceinline__ float& at(typename Vec<V>::T& v, int j);
+template <>
+__device__ __forceinline__ float& at<4>(F4& v, int j) { return v.v[j]; }
+template <>
+__device__ __forceinline__ float& at<1>(float& v, int) { return v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// bn_stats: per chunk (pivot, sum(x-pivot), sum((x-pivot)^2), count) per channel
+// ws layout: [chunks][4][C]
+// ---------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t M, int C, int cols,
+                                                          int rpp, int64_t rows_per_chunk, float* __restrict__ ws) {
+  __shared__ float red[2][256 * 4];
+  const int t = threadIdx.x;
+  const int col = t % cols, rg = t / cols;
+  const bool active = rg < rpp;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t r1 = min(M, r0 + rows_per_chunk);
+  typename Vec<V>::T piv, s1, s2;
+  for (int j = 0; j < V; ++j) at<V>(piv, j) = at<V>(s1, j) = at<V>(s2, j) = 0.f;
+  if (r0 < M) piv = Vec<V>::load(x + r0 * C + col * V);
+  if (active) {
+    for (int64_t r = r0 + rg; r < r1; r += rpp) {
+      typename Vec<V>::T v = Vec<V>::load(x + r * C + col * V);
+      for (int j = 0; j < V; ++j) {
+        float dlt = at<V>(v, j) - at<V>(piv, j);
+        at<V>(s1, j) += dlt;
+        at<V>(s2, j) += dlt * dlt;
+      }
+    }
+  }
+  for (int j = 0; j < V; ++j) {
+    red[0][t * 4 + j] = active ? at<V>(s1, j) : 0.f;
+    red[1][t * 4 + j] = active ? at<V>(s2, j) : 0.f;
+  }
+  __syncthreads();
+  if (t < cols) {
+    float* out = ws + (size_t)blockIdx.x * 4 * C;
+    for (int j = 0; j < V; ++j) {
+      float a = 0.f, b = 0.f;
+      for (int g = 0; g < rpp; ++g) {
+        a += red[0][(g * cols + t) * 4 + j];
+        b += red[1][(g * cols + t) * 4 + j];
+      }
+      const int c = t * V + j;
+      out[c] = at<V>(piv, j);
+      out[C + c] = a;
+      out[2 * C + c] = b;
+      out[3 * C + c] = (float)(r1 > r0 ? (r1 - r0) : 0);
+    }
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // Chan et al. pairwise combination, in double, fixed chunk order
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const float* p = ws + (size_t)k * 4 * C;
+    const double nb = p[3 * C + c];
+    if (nb <= 0.0) continue;
+    const double s1 = p[C + c], s2 = p[2 * C + c];
+    const double mb = (double)p[c] + s1 / nb;
+    const double m2b = s2 - s1 * s1 / nb;
+    const double delta = mb - mean, nt = n + nb;
+    mean += delta * nb / nt;
+    m2 += m2b + delta * delta * n * nb / nt;
+    n = nt;
+  }
+  const double var = m2 / (double)M;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean) {
+    const double unbiased = M > 1 ? m2 / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y = act(x*scale + shift) * row_scale[n, c]
+// ---------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t total_v, int C,
+                                                          const float* scale, const float* shift, int act,
+                                                          const float* row_scale, int64_t rows_per_n,
+                                                          float* __restrict__ y) {
+  const int cols = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols) * V;
+    typename Vec<V>::T v = Vec<V>::load(x + i * V);
+    for (int j = 0; j < V; ++j) {
+      float u = at<V>(v, j);
+      if (scale) u = u * scale[c + j] + shift[c + j];
+      u = act_fwd(u, act);
+      if (row_scale) u *= row_scale[(row / rows_per_n) * C + c + j];
+      at<V>(v, j) = u;
+    }
+    Vec<V>::store(y + i * V, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward of h = act(x*scale+shift): reduce pass -> ws [chunks][2][C] of (sum g, sum g*xhat)
+// ---------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                                  int64_t M, int C, int cols, int rpp,
+                                                                  int64_t rows_per_chunk, const float* scale,
+                                                                  const float* shift, int act, const float* mean,
+                                                                  const float* rstd, float* __restrict__ ws) {
+  __shared__ float red[2][256 * 4];
+  const int t = threadIdx.x;
+  const int col = t % cols, rg = t / cols;
+  const bool active = rg < rpp;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t r1 = min(M, r0 + rows_per_chunk);
+  float sg[V], sgx[V], sc[V], sh[V], mu[V], rs[V];
+  for (int j = 0; j < V; ++j) {
+    sg[j] = sgx[j] = 0.f;
+    const int c = col * V + j;
+    sc[j] = scale[c];
+    sh[j] = shift[c];
+    mu[j] = mean[c];
+    rs[j] = rstd[c];
+  }
+  if (active) {
+    for (int64_t r = r0 + rg; r < r1; r += rpp) {
+      typename Vec<V>::T xv = Vec<V>::load(x + r * C + col * V);
+      typename Vec<V>::T gv = Vec<V>::load(dh + r * C + col * V);
+      for (int j = 0; j < V; ++j) {
+        const float xx = at<V>(xv, j);
+        const float g = at<V>(gv, j) * act_grad(xx * sc[j] + sh[j], act);
+        sg[j] += g;
+        sgx[j] += g * (xx - mu[j]) * rs[j];
+      }
+    }
+  }
+  for (int j = 0; j < V; ++j) {
+    red[0][t * 4 + j] = active ? sg[j] : 0.f;
+    red[1][t * 4 + j] = active ? sgx[j] : 0.f;
+  }
+  __syncthreads();
+  if (t < cols) {
+    float* out = ws + (size_t)blockIdx.x * 2 * C;
+    for (int j = 0; j < V; ++j) {
+      float a = 0.f, b = 0.f;
+      for (int g = 0; g < rpp; ++g) {
+        a += red[0][(g * cols + t) * 4 + j];
+        b += red[1][(g * cols + t) * 4 + j];
+      }
+      out[t * V + j] = a;
+      out[C + t * V + j] = b;
+    }
+  }
+}
+
+// coef layout (tail of ws): [2][C] = (mean g, mean g*xhat)
+__global__ void affine_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M, float* dgamma,
+                                           float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    a += ws[(size_t)k * 2 * C + c];
+    b += ws[(size_t)k * 2 * C + C + c];
+  }
+  if (dbeta) dbeta[c] += (float)a;
+  if (dgamma) dgamma[c] += (float)b;
+  coef[c] = (float)(a / (double)M);
+  coef[C + c] = (float)(b / (double)M);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                                int64_t total_v, int C, const float* scale,
+                                                                const float* shift, int act, const float* mean,
+                                                                const float* rstd, const float* coef,
+                                                                const float* drop, int64_t rows_per_n,
+                                                                const float* __restrict__ add, float* __restrict__ dx) {
+  const int cols = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols) * V;
+    typename Vec<V>::T xv = Vec<V>::load(x + i * V);
+    typename Vec<V>::T gv = Vec<V>::load(dh + i * V);
+    typename Vec<V>::T av;
+    if (add) av = Vec<V>::load(add + i * V);
+    for (int j = 0; j < V; ++j) {
+      const float xx = at<V>(xv, j);
+      const float sc = scale ? scale[c + j] : 1.f, sh = scale ? shift[c + j] : 0.f;
+      float g = at<V>(gv, j) * act_grad(xx * sc + sh, act);
+      if (coef) g = g - coef[c + j] - (xx - mean[c + j]) * rstd[c + j] * coef[C + c + j];
+      g *= sc;
+      if (drop) g *= drop[(row / rows_per_n) * C + c + j];
+      if (add) g += at<V>(av, j);
+      at<V>(gv, j) = g;
+    }
+    Vec<V>::store(dx + i * V, gv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gate
+// ---------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ ab, const float* __restrict__ res,
+                                                        int64_t total_v, int C, int act, float* __restrict__ out) {
+  const int cols = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols) * V;
+    typename Vec<V>::T a = Vec<V>::load(ab + row * 2 * C + c);
+    typename Vec<V>::T b = Vec<V>::load(ab + row * 2 * C + C + c);
+    typename Vec<V>::T r;
+    if (res) r = Vec<V>::load(res + i * V);
+    for (int j = 0; j < V; ++j) {
+      float o = act_fwd(at<V>(a, j), act) * sigmoidf_(at<V>(b, j));
+      if (res) o += at<V>(r, j);
+      at<V>(a, j) = o;
+    }
+    Vec<V>::store(out + i * V, a);
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ab,
+                                                        int64_t total_v, int C, int act, float* __restrict__ dab) {
+  const int cols = C / V;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols) * V;
+    typename Vec<V>::T a = Vec<V>::load(ab + row * 2 * C + c);
+    typename Vec<V>::T b = Vec<V>::load(ab + row * 2 * C + C + c);
+    typename Vec<V>::T g = Vec<V>::load(dout + i * V);
+    for (int j = 0; j < V; ++j) {
+      const float s = sigmoidf_(at<V>(b, j));
+      const float aa = at<V>(a, j), gg = at<V>(g, j);
+      at<V>(a, j) = gg * s * act_grad(aa, act);
+      at<V>(b, j) = gg * act_fwd(aa, act) * s * (1.f - s);
+    }
+    Vec<V>::store(dab + row * 2 * C + c, a);
+    Vec<V>::store(dab + row * 2 * C + C + c, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small glue
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_from_out_kernel(const float* dy, const float* y, int64_t n, int act,
+                                                                float* dx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dx[i] = dy[i] * act_grad_from_out(y[i], act);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* a, const float* row_scale, int64_t rows_per_n,
+                                                              int C, const float* b, int64_t total, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / C;
+    const int c = (int)(i - row * C);
+    float v = a[i];
+    if (row_scale) v *= row_scale[(row / rows_per_n) * C + c];
+    if (b) v += b[i];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t R, int64_t P, float* out, int accumulate) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  float s = 0.f;
+  for (int64_t r = 0; r < R; ++r) s += x[r * P + p];
+  out[p] = accumulate ? out[p] + s : s;
+}
+
+static bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return C % 4 == 0 && C / 4 <= 256 && al(a) && al(b) && al(c) && al(d);
+}
+
+}  // namespace lvae
+
+using namespace lvae;
+
+extern "C" size_t lvae_bn_stats_workspace(int64_t M, int32_t C) {
+  (void)M;
+  return (size_t)(kMaxChunks * 4 + 2) * (size_t)C * sizeof(float);
+}
+
+extern "C" int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                 float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream) {
+  LVAE_REQUIRE(x && scale && shift && mean && rstd && workspace, LVAE_EINVAL, "lvae_bn_stats_f32: null pointer");
+  LVAE_REQUIRE(M > 0 && C > 0 && C <= 256 * 4, LVAE_EINVAL, "lvae_bn_stats_f32: bad M=%lld C=%d", (long long)M, C);
+  LVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), LVAE_EINVAL, "lvae_bn_stats_f32: running pair");
+  LVAE_REQUIRE(workspace_bytes >= lvae_bn_stats_workspace(M, C), LVAE_EWORKSPACE, "lvae_bn_stats_f32: workspace");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = static_cast<float*>(workspace);
+  const bool v4 = vec_ok(C, x);
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_bn_stats_f32: C=%d needs C%%4==0 above 256 channels", C);
+  RowMap rm = row_map(C, v4 ? 4 : 1);
+  const int chunks = chunk_count(M, rm.rpp);
+  int64_t rpc = (M + chunks - 1) / chunks;
+  rpc = (rpc + rm.rpp - 1) / rm.rpp * rm.rpp;
+  const int used = (int)((M + rpc - 1) / rpc);
+  if (v4)
+    hipLaunchKernelGGL(bn_partial_kernel<4>, dim3(used), dim3(256), 0, s, x, M, C, rm.cols, rm.rpp, rpc, ws);
+  else
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(used), dim3(256), 0, s, x, M, C, rm.cols, rm.rpp, rpc, ws);
+  LVAE_LAUNCH_CHECK("bn_partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale, shift, mean, rstd);
+  LVAE_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
+extern "C" int lvae_bn_eval_coeffs_f32(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  LVAE_REQUIRE(C > 0 && running_mean && running_var && scale && shift, LVAE_EINVAL, "lvae_bn_eval_coeffs_f32: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  LVAE_LAUNCH_CHECK("bn_eval_coeffs");
+  return 0;
+}
+
+extern "C" int lvae_affine_act_f32(const float* x, int64_t M, int32_t C, const float* scale, const float* shift,
+                                   int32_t act, const float* row_scale, int64_t rows_per_n, float* y, void* stream) {
+  LVAE_REQUIRE(x && y && M > 0 && C > 0, LVAE_EINVAL, "lvae_affine_act_f32: bad args");
+  LVAE_REQUIRE((scale == nullptr) == (shift == nullptr), LVAE_EINVAL, "lvae_affine_act_f32: scale/shift pair");
+  LVAE_REQUIRE(!row_scale || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_f32: rows_per_n");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(C, x, y)) {
+    const int64_t tv = M * (C / 4);
+    hipLaunchKernelGGL(affine_act_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, x, tv, C, scale, shift, act,
+                       row_scale, rows_per_n, y);
+  } else {
+    const int64_t tv = M * C;
+    hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, x, tv, C, scale, shift, act,
+                       row_scale, rows_per_n, y);
+  }
+  LVAE_LAUNCH_CHECK("affine_act");
+  return 0;
+}
+
+extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t M, int32_t C, const float* scale,
+                                       const float* shift, int32_t act, int32_t bn_train, const float* mean,
+                                       const float* rstd, float* dgamma, float* dbeta, const float* drop,
+                                       int64_t rows_per_n, const float* add, float* dx, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  LVAE_REQUIRE(dh && x && dx && M > 0 && C > 0, LVAE_EINVAL, "lvae_affine_act_bwd_f32: bad args");
+  LVAE_REQUIRE((scale == nullptr) == (shift == nullptr), LVAE_EINVAL, "lvae_affine_act_bwd_f32: scale/shift pair");
+  LVAE_REQUIRE(!drop || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_bwd_f32: rows_per_n");
+  hipStream_t s = (hipStream_t)stream;
+  const bool v4 = vec_ok(C, x, dh, dx, add);
+  float* coef = nullptr;
+  if (bn_train) {
+    LVAE_REQUIRE(scale && mean && rstd && workspace, LVAE_EINVAL, "lvae_affine_act_bwd_f32: bn_train needs stats");
+    LVAE_REQUIRE(workspace_bytes >= lvae_bn_stats_workspace(M, C), LVAE_EWORKSPACE, "lvae_affine_act_bwd_f32: workspace");
+    LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_affine_act_bwd_f32: C=%d unsupported", C);
+    float* ws = static_cast<float*>(workspace);
+    RowMap rm = row_map(C, v4 ? 4 : 1);
+    const int chunks = chunk_count(M, rm.rpp);
+    int64_t rpc = (M + chunks - 1) / chunks;
+    rpc = (rpc + rm.rpp - 1) / rm.rpp * rm.rpp;
+    const int used = (int)((M + rpc - 1) / rpc);
+    coef = ws + (size_t)kMaxChunks * 4 * C;
+    if (v4)
+      hipLaunchKernelGGL(affine_bwd_partial_kernel<4>, dim3(used), dim3(256), 0, s, dh, x, M, C, rm.cols, rm.rpp, rpc,
+                         scale, shift, act, mean, rstd, ws);
+    else
+      hipLaunchKernelGGL(affine_bwd_partial_kernel<1>, dim3(used), dim3(256), 0, s, dh, x, M, C, rm.cols, rm.rpp, rpc,
+                         scale, shift, act, mean, rstd, ws);
+    LVAE_LAUNCH_CHECK("affine_bwd_partial");
+    hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, used, C, M, dgamma, dbeta, coef);
+    LVAE_LAUNCH_CHECK("affine_bwd_finalize");
+  }
+  if (v4) {
+    const int64_t tv = M * (C / 4);
+    hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dh, x, tv, C, scale, shift,
+                       act, mean, rstd, coef, drop, rows_per_n, add, dx);
+  } else {
+    const int64_t tv = M * C;
+    hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dh, x, tv, C, scale, shift,
+                       act, mean, rstd, coef, drop, rows_per_n, add, dx);
+  }
+  LVAE_LAUNCH_CHECK("affine_bwd_apply");
+  return 0;
+}
+
+extern "C" int lvae_gate_fwd_f32(const float* ab, const float* res, int64_t M, int32_t C, int32_t act, float* out,
+                                 void* stream) {
+  LVAE_REQUIRE(ab && out && M > 0 && C > 0, LVAE_EINVAL, "lvae_gate_fwd_f32: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(C, ab, res, out)) {
+    const int64_t tv = M * (C / 4);
+    hipLaunchKernelGGL(gate_fwd_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, ab, res, tv, C, act, out);
+  } else {
+    const int64_t tv = M * C;
+    hipLaunchKernelGGL(gate_fwd_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, ab, res, tv, C, act, out);
+  }
+  LVAE_LAUNCH_CHECK("gate_fwd");
+  return 0;
+}
+
+extern "C" int lvae_gate_bwd_f32(const float* dout, const float* ab, int64_t M, int32_t C, int32_t act, float* dab,
+                                 void* stream) {
+  LVAE_REQUIRE(dout && ab && dab && M > 0 && C > 0, LVAE_EINVAL, "lvae_gate_bwd_f32: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(C, ab, dout, dab)) {
+    const int64_t tv = M * (C / 4);
+    hipLaunchKernelGGL(gate_bwd_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dout, ab, tv, C, act, dab);
+  } else {
+    const int64_t tv = M * C;
+    hipLaunchKernelGGL(gate_bwd_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dout, ab, tv, C, act, dab);
+  }
+  LVAE_LAUNCH_CHECK("gate_bwd");
+  return 0;
+}
+
+extern "C" int lvae_act_bwd_from_out_f32(const float* dy, const float* y, int64_t n, int32_t act, float* dx, void* stream) {
+  LVAE_REQUIRE(dy && y && dx && n > 0, LVAE_EINVAL, "lvae_act_bwd_from_out_f32: bad args");
+  hipLaunchKernelGGL(act_bwd_from_out_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n, act, dx);
+  LVAE_LAUNCH_CHECK("act_bwd_from_out");
+  return 0;
+}
+
+extern "C" int lvae_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  LVAE_REQUIRE(a && b && out && n > 0, LVAE_EINVAL, "lvae_add_f32: bad args");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  LVAE_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int lvae_scale_rows_add_f32(const float* a, const float* row_scale, int64_t rows_per_n, int32_t C,
+                                       const float* b, int64_t M, float* out, void* stream) {
+  LVAE_REQUIRE(a && out && M > 0 && C > 0 && (!row_scale || rows_per_n > 0), LVAE_EINVAL, "lvae_scale_rows_add_f32: bad args");
+  const int64_t total = M * C;
+  hipLaunchKernelGGL(scale_rows_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, row_scale,
+                     rows_per_n, C, b, total, out);
+  LVAE_LAUNCH_CHECK("scale_rows_add");
+  return 0;
+}
+
+extern "C" int lvae_colsum_f32(const float* x, int64_t R, int64_t P, float* out, int32_t accumulate, void* stream) {
+  LVAE_REQUIRE(x && out && R > 0 && P > 0, LVAE_EINVAL, "lvae_colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, R, P, out,
+                     accumulate);
+  LVAE_LAUNCH_CHECK("colsum");
+  return 0;
+}

@@ -1,0 +1,185 @@
+// NormalStochasticBlock2d elementwise core (lib/stochastic.py:45-99, 209-226): reparameterised sample, log p(z),
+// log q(z), Monte-Carlo and analytical KL with their per-sample and per-pixel reductions, and the hand-written
+// backward. One workgroup per sample; the Z channels of a pixel are contiguous (NHWC) so the per-pixel KL sum is
+// a shuffle reduction over Z lanes. HBM-bound: reads p, q, eps once and writes z once.
+#include "lvae_common.h"
+
+namespace lvae {
+
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+
+struct StochArgs {
+  const float* p;
+  const float* q;
+  const float* eps;
+  int p_bcast, N, HW, Z, mode, analytical;
+};
+
+__device__ __forceinline__ float normal_logprob(float z, float mu, float lv) {
+  // torch.distributions.Normal(mu, exp(lv/2)).log_prob(z): var = std^2, log std = log(std)
+  const float sd = expf(0.5f * lv);
+  const float d = z - mu;
+  return -(d * d) / (2.f * sd * sd) - logf(sd) - kLogSqrt2Pi;
+}
+
+__device__ __forceinline__ float normal_kl(float qmu, float qlv, float pmu, float plv) {
+  const float qs = expf(0.5f * qlv), ps = expf(0.5f * plv);
+  const float r = qs / ps, vr = r * r;
+  const float t = (qmu - pmu) / ps;
+  return 0.5f * (vr + t * t - 1.f - logf(vr));
+}
+
+__global__ __launch_bounds__(256) void stoch_fwd_kernel(StochArgs a, float* __restrict__ z_out, float* logprob_p,
+                                                         float* logprob_q, float* kl_samplewise, float* kl_spatial) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const int Z = a.Z, per = a.HW * Z;
+  const float* pn = a.p + (a.p_bcast ? 0 : (size_t)n * a.HW * 2 * Z);
+  const float* qn = a.q ? a.q + (size_t)n * a.HW * 2 * Z : nullptr;
+  const bool zpow2 = (Z & (Z - 1)) == 0 && Z <= 64;
+  float s_lp = 0.f, s_lq = 0.f, s_kl = 0.f;
+  // iterate in whole 256-element passes so that every lane of a wave takes part in the shuffles
+  const int passes = (per + 255) / 256;
+  for (int it = 0; it < passes; ++it) {
+    const int e = it * 256 + t;
+    const bool ok = e < per;
+    float kan = 0.f;
+    int pix = 0;
+    if (ok) {
+      pix = e / Z;
+      const int c = e - pix * Z;
+      const float pmu = pn[(size_t)pix * 2 * Z + c], plv = pn[(size_t)pix * 2 * Z + Z + c];
+      float smu = pmu, slv = plv, qmu = 0.f, qlv = 0.f;
+      if (qn) {
+        qmu = qn[(size_t)pix * 2 * Z + c];
+        qlv = qn[(size_t)pix * 2 * Z + Z + c];
+        smu = qmu;
+        slv = qlv;
+      }
+      float z;
+      const size_t zi = (size_t)n * per + e;
+      if (a.mode == 0) z = smu + expf(0.5f * slv) * a.eps[zi];
+      else if (a.mode == 1) z = smu;
+      else z = a.eps[zi];  // forced latent is passed through the eps pointer
+      z_out[zi] = z;
+      const float lp = normal_logprob(z, pmu, plv);
+      s_lp += lp;
+      if (qn) {
+        const float lq = normal_logprob(z, qmu, qlv);
+        s_lq += lq;
+        kan = normal_kl(qmu, qlv, pmu, plv);
+        s_kl += a.analytical ? kan : (lq - lp);
+      }
+    }
+    if (qn && kl_spatial) {
+      if (zpow2) {
+        float v = kan;
+        for (int o = Z >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (ok && (e % Z) == 0) kl_spatial[(size_t)n * a.HW + pix] = v;
+      }
+    }
+  }
+  if (qn && kl_spatial && !zpow2) {
+    for (int pix = t; pix < a.HW; pix += 256) {
+      float v = 0.f;
+      for (int c = 0; c < Z; ++c)
+        v += normal_kl(qn[(size_t)pix * 2 * Z + c], qn[(size_t)pix * 2 * Z + Z + c], pn[(size_t)pix * 2 * Z + c],
+                       pn[(size_t)pix * 2 * Z + Z + c]);
+      kl_spatial[(size_t)n * a.HW + pix] = v;
+    }
+  }
+  s_lp = block_sum_256(s_lp, red);
+  if (t == 0) logprob_p[n] = s_lp;
+  if (qn) {
+    s_lq = block_sum_256(s_lq, red);
+    s_kl = block_sum_256(s_kl, red);
+    if (t == 0) {
+      logprob_q[n] = s_lq;
+      kl_samplewise[n] = s_kl;
+    }
+  }
+}
+
+struct StochBwdArgs {
+  const float *p, *q, *eps, *z, *dz, *g_lp, *g_lq, *g_kl, *g_ks;
+  int p_bcast, N, HW, Z, mode, analytical;
+};
+
+__global__ __launch_bounds__(256) void stoch_bwd_kernel(StochBwdArgs a, float* __restrict__ dp, float* __restrict__ dq) {
+  const int Z = a.Z;
+  const int64_t per = (int64_t)a.HW * Z, total = per * a.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / per);
+    const int e = (int)(i - (int64_t)n * per);
+    const int pix = e / Z, c = e - pix * Z;
+    const size_t pb = ((a.p_bcast ? 0 : (size_t)n * a.HW) + pix) * 2 * Z, ob = ((size_t)n * a.HW + pix) * 2 * Z;
+    const float pmu = a.p[pb + c], plv = a.p[pb + Z + c];
+    const float z = a.z[i];
+    const float dzu = a.dz ? a.dz[i] : 0.f;
+    const float glp = a.g_lp ? a.g_lp[n] : 0.f;
+    const float ivp = expf(-plv);  // 1/sigma_p^2
+    const float dpz = z - pmu;
+    if (a.q) {
+      const float qmu = a.q[ob + c], qlv = a.q[ob + Z + c];
+      const float gkl = a.g_kl ? a.g_kl[n] : 0.f;
+      const float G_lp = glp - (a.analytical ? 0.f : gkl);
+      const float G_lq = (a.g_lq ? a.g_lq[n] : 0.f) + (a.analytical ? 0.f : gkl);
+      const float G_an = (a.g_ks ? a.g_ks[(size_t)n * a.HW + pix] : 0.f) + (a.analytical ? gkl : 0.f);
+      const float ivq = expf(-qlv);
+      const float dqz = z - qmu;
+      const float Gz = dzu - G_lp * dpz * ivp - G_lq * dqz * ivq;
+      const float dmu = qmu - pmu;
+      const float vr = expf(qlv - plv);
+      float dpmu = G_lp * dpz * ivp - G_an * dmu * ivp;
+      float dplv = G_lp * 0.5f * (dpz * dpz * ivp - 1.f) + G_an * 0.5f * (1.f - vr - dmu * dmu * ivp);
+      float dqmu = G_lq * dqz * ivq + G_an * dmu * ivp;
+      float dqlv = G_lq * 0.5f * (dqz * dqz * ivq - 1.f) + G_an * 0.5f * (vr - 1.f);
+      if (a.mode <= 1) dqmu += Gz;
+      if (a.mode == 0) dqlv += Gz * 0.5f * expf(0.5f * qlv) * a.eps[i];
+      dp[ob + c] = dpmu;
+      dp[ob + Z + c] = dplv;
+      dq[ob + c] = dqmu;
+      dq[ob + Z + c] = dqlv;
+    } else {
+      const float Gz = dzu - glp * dpz * ivp;
+      float dpmu = glp * dpz * ivp, dplv = glp * 0.5f * (dpz * dpz * ivp - 1.f);
+      if (a.mode <= 1) dpmu += Gz;
+      if (a.mode == 0) dplv += Gz * 0.5f * expf(0.5f * plv) * a.eps[i];
+      dp[ob + c] = dpmu;
+      dp[ob + Z + c] = dplv;
+    }
+  }
+}
+
+}  // namespace lvae
+
+using namespace lvae;
+
+extern "C" int lvae_normal_stochastic_fwd_f32(const float* p, int32_t p_bcast, const float* q, const float* eps,
+                                              int32_t N, int32_t HW, int32_t Z, int32_t mode, int32_t analytical_kl,
+                                              float* z, float* logprob_p, float* logprob_q, float* kl_samplewise,
+                                              float* kl_spatial, void* stream) {
+  LVAE_REQUIRE(p && z && logprob_p && N > 0 && HW > 0 && Z > 0, LVAE_EINVAL, "lvae_normal_stochastic_fwd_f32: bad args");
+  LVAE_REQUIRE(mode >= 0 && mode <= 2, LVAE_EINVAL, "lvae_normal_stochastic_fwd_f32: mode %d", mode);
+  LVAE_REQUIRE(mode == 1 || eps, LVAE_EINVAL, "lvae_normal_stochastic_fwd_f32: eps / forced latent missing");
+  LVAE_REQUIRE(!q || (logprob_q && kl_samplewise), LVAE_EINVAL, "lvae_normal_stochastic_fwd_f32: q outputs missing");
+  StochArgs a{p, q, eps, p_bcast, N, HW, Z, mode, analytical_kl};
+  hipLaunchKernelGGL(stoch_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a, z, logprob_p, logprob_q,
+                     kl_samplewise, kl_spatial);
+  LVAE_LAUNCH_CHECK("normal_stochastic_fwd");
+  return 0;
+}
+
+extern "C" int lvae_normal_stochastic_bwd_f32(const float* p, int32_t p_bcast, const float* q, const float* eps,
+                                              const float* z, const float* dz, const float* g_lp, const float* g_lq,
+                                              const float* g_kl, const float* g_ks, int32_t N, int32_t HW, int32_t Z,
+                                              int32_t mode, int32_t analytical_kl, float* dp, float* dq, void* stream) {
+  LVAE_REQUIRE(p && z && dp && N > 0 && HW > 0 && Z > 0, LVAE_EINVAL, "lvae_normal_stochastic_bwd_f32: bad args");
+  LVAE_REQUIRE((q == nullptr) == (dq == nullptr), LVAE_EINVAL, "lvae_normal_stochastic_bwd_f32: q/dq mismatch");
+  LVAE_REQUIRE(mode != 0 || eps, LVAE_EINVAL, "lvae_normal_stochastic_bwd_f32: eps missing");
+  StochBwdArgs a{p, q, eps, z, dz, g_lp, g_lq, g_kl, g_ks, p_bcast, N, HW, Z, mode, analytical_kl};
+  const int64_t total = (int64_t)N * HW * Z;
+  hipLaunchKernelGGL(stoch_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, dp, dq);
+  LVAE_LAUNCH_CHECK("normal_stochastic_bwd");
+  return 0;
+}

@@ -1,0 +1,363 @@
+"""Tensor-level wrappers over the C ABI (one Python function per kernel entry point).
+
+Activations are 4-D torch tensors stored NHWC: shape (N, H, W, C), contiguous, float32, on the GPU. No arithmetic
+happens in Python or in torch ops here: every function launches hand-written HIP kernels on torch's current
+stream. Buffers (outputs, workspaces) come from torch's caching allocator, which is graph-capture safe.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+from ._C import ACT, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, call, ptr, stream_ptr
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """A per-device scratch buffer, grown on demand. Kernels run in stream order, so one buffer is enough."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream if False else 0)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes or buf.device != device:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _chk_nhwc(t, name):
+    if t.dim() != 4 or not t.is_contiguous() or t.dtype != torch.float32:
+        raise _C.LvaeHipError("%s must be a contiguous float32 (N,H,W,C) tensor, got shape %s strides %s %s" %
+                              (name, tuple(t.shape), tuple(t.stride()), t.dtype))
+
+
+class ConvGeom:
+    """Geometry of one convolution call site plus the strides of its weight tensor.
+
+    `weight` is the nn.Parameter in the reference's logical shape — (Cout,Cin,KH,KW) for nn.Conv2d,
+    (Cin,Cout,KH,KW) for nn.ConvTranspose2d — in ANY tap-linear memory layout; the arena packs it as
+    [KH][KW][Cin][Cout] so that forward reads are n-contiguous and dgrad reads k-contiguous float4s.
+    """
+
+    def __init__(self, weight, stride=1, pad=0, transposed=False, output_padding=0):
+        self.transposed = bool(transposed)
+        if transposed:
+            self.Cin, self.Cout, self.KH, self.KW = weight.shape
+            s_ci, s_co, s_kh, s_kw = weight.stride()
+        else:
+            self.Cout, self.Cin, self.KH, self.KW = weight.shape
+            s_co, s_ci, s_kh, s_kw = weight.stride()
+        if self.KH * self.KW > 1 and s_kh != self.KW * s_kw:
+            raise _C.LvaeHipError("weight layout is not tap-linear (strides %s)" % (tuple(weight.stride()),))
+        self.s_tap, self.s_ci, self.s_co = (s_kw if self.KH * self.KW > 1 else 0), s_ci, s_co
+        self.stride, self.pad, self.output_padding = int(stride), int(pad), int(output_padding)
+
+    def out_size(self, H, W):
+        if self.transposed:
+            return ((H - 1) * self.stride - 2 * self.pad + self.KH + self.output_padding,
+                    (W - 1) * self.stride - 2 * self.pad + self.KW + self.output_padding)
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+
+def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, bias=None, in_scale=None, in_shift=None,
+          in_act=None, out_scale=None, out_act=None, y=None):
+    d = ConvDesc()
+    d.x, d.x2 = ptr(x), ptr(x2)
+    d.C1, d.C2 = x.shape[3], (x2.shape[3] if x2 is not None else 0)
+    d.w, d.w_stap, d.w_sk, d.w_sn = ptr(weight), g.s_tap, k_stride, n_stride
+    d.bias, d.in_scale, d.in_shift = ptr(bias), ptr(in_scale), ptr(in_shift)
+    d.in_act, d.out_scale, d.out_act = ACT[in_act], ptr(out_scale), ACT[out_act]
+    d.y = ptr(y)
+    d.N, d.H, d.W, d.OH, d.OW, d.Cout = N, H, W, OH, OW, Cout
+    d.KH, d.KW, d.stride, d.pad, d.gather = g.KH, g.KW, g.stride, g.pad, gather
+    return d
+
+
+def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None):
+    """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC."""
+    _chk_nhwc(x, 'x')
+    N, H, W, C1 = x.shape
+    if x2 is not None:
+        _chk_nhwc(x2, 'x2')
+        assert x2.shape[:3] == x.shape[:3]
+    if C1 + (x2.shape[3] if x2 is not None else 0) != g.Cin:
+        raise _C.LvaeHipError("conv2d: input has %d channels, weight expects %d" % (C1 + (x2.shape[3] if x2 is not None else 0), g.Cin))
+    OH, OW = g.out_size(H, W)
+    y = torch.empty((N, OH, OW, g.Cout), dtype=torch.float32, device=x.device)
+    d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
+              GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
+    call('lvae_conv2d_f32', C.byref(d), stream_ptr())
+    return y
+
+
+def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
+    """Gradient w.r.t. the conv input (before any fused input transform). dy NHWC (N,OH,OW,Cout) -> (N,H,W,Cin).
+    out_scale (N,Cin) multiplies the result per (sample, channel) (Dropout2d mask of the producer).
+    ci_range=(a,b) restricts the result to input channels [a,b) (the two halves of a fused channel concat)."""
+    _chk_nhwc(dy, 'dy')
+    N, OH, OW, Co = dy.shape
+    H, W = in_hw
+    a, b = ci_range if ci_range is not None else (0, g.Cin)
+    dx = torch.empty((N, H, W, b - a), dtype=torch.float32, device=dy.device)
+    d = _desc(g, weight, dy, None, N, OH, OW, H, W, b - a, g.s_co, g.s_ci,
+              GATHER_CONV if g.transposed else GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
+    d.w = ptr(weight) + 4 * a * g.s_ci
+    call('lvae_conv2d_f32', C.byref(d), stream_ptr())
+    return dx
+
+
+def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, in_shift=None, in_act=None):
+    """dweight += d/dw, dbias += d/db for the convolution of `conv2d` with the same fused input transform.
+    dweight must have the same strides as weight (a view of the gradient arena)."""
+    _chk_nhwc(x, 'x')
+    _chk_nhwc(dy, 'dy')
+    N, H, W, _ = x.shape
+    OH, OW = dy.shape[1], dy.shape[2]
+    if tuple(dweight.stride()) != tuple(weight.stride()):
+        raise _C.LvaeHipError("conv2d_wgrad: gradient strides %s differ from weight strides %s" %
+                              (tuple(dweight.stride()), tuple(weight.stride())))
+    d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
+              GATHER_TRANSPOSED if g.transposed else GATHER_CONV, None, in_scale, in_shift, in_act)
+    need = _C.load().lvae_conv2d_wgrad_workspace(C.byref(d))
+    ws = workspace(need, x.device)
+    call('lvae_conv2d_wgrad_f32', C.byref(d), ptr(dy), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def bn_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """Training-mode BatchNorm statistics of NHWC x. Returns (scale, shift, mean, rstd), each (C,)."""
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    out = torch.empty((4, Cn), dtype=torch.float32, device=x.device)
+    need = _C.load().lvae_bn_stats_workspace(M, Cn)
+    ws = workspace(need, x.device)
+    call('lvae_bn_stats_f32', ptr(x), M, Cn, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
+         ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ws.data_ptr(), ws.numel(), stream_ptr())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=1e-5):
+    Cn = running_mean.numel()
+    out = torch.empty((2, Cn), dtype=torch.float32, device=running_mean.device)
+    call('lvae_bn_eval_coeffs_f32', Cn, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, ptr(out[0]),
+         ptr(out[1]), stream_ptr())
+    return out[0], out[1]
+
+
+def affine_act(x, scale, shift, act, row_scale=None):
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    y = torch.empty_like(x)
+    rows_per_n = M // x.shape[0]
+    call('lvae_affine_act_f32', ptr(x), M, Cn, ptr(scale), ptr(shift), ACT[act], ptr(row_scale), rows_per_n, ptr(y),
+         stream_ptr())
+    return y
+
+
+def affine_act_bwd(dh, x, scale, shift, act, bn_train, mean=None, rstd=None, dgamma=None, dbeta=None, drop=None, add=None):
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    dx = torch.empty_like(x)
+    need = _C.load().lvae_bn_stats_workspace(M, Cn)
+    ws = workspace(need, x.device)
+    rows_per_n = M // x.shape[0]
+    call('lvae_affine_act_bwd_f32', ptr(dh), ptr(x), M, Cn, ptr(scale), ptr(shift), ACT[act], int(bool(bn_train)),
+         ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(drop), rows_per_n, ptr(add), ptr(dx), ws.data_ptr(),
+         ws.numel(), stream_ptr())
+    return dx
+
+
+def gate_fwd(ab, res, act):
+    Cn = ab.shape[-1] // 2
+    M = ab.numel() // (2 * Cn)
+    out = torch.empty(ab.shape[:-1] + (Cn,), dtype=torch.float32, device=ab.device)
+    call('lvae_gate_fwd_f32', ptr(ab), ptr(res), M, Cn, ACT[act], ptr(out), stream_ptr())
+    return out
+
+
+def gate_bwd(dout, ab, act):
+    Cn = ab.shape[-1] // 2
+    M = ab.numel() // (2 * Cn)
+    dab = torch.empty_like(ab)
+    call('lvae_gate_bwd_f32', ptr(dout), ptr(ab), M, Cn, ACT[act], ptr(dab), stream_ptr())
+    return dab
+
+
+def act_bwd_from_out(dy, y, act):
+    dx = torch.empty_like(y)
+    call('lvae_act_bwd_from_out_f32', ptr(dy), ptr(y), y.numel(), ACT[act], ptr(dx), stream_ptr())
+    return dx
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    call('lvae_add_f32', ptr(a), ptr(b), a.numel(), ptr(out), stream_ptr())
+    return out
+
+
+def scale_rows_add(a, row_scale, b, out=None):
+    """out = a * row_scale[n, c] + b  (either optional; with neither it is a device copy into `out`)."""
+    Cn = a.shape[-1]
+    M = a.numel() // Cn
+    if out is None:
+        out = torch.empty_like(a)
+    call('lvae_scale_rows_add_f32', ptr(a), ptr(row_scale), M // a.shape[0], Cn, ptr(b), M, ptr(out), stream_ptr())
+    return out
+
+
+def colsum(x2d, out, accumulate):
+    R, P = x2d.shape
+    call('lvae_colsum_f32', ptr(x2d), R, P, ptr(out), int(bool(accumulate)), stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def normal_stochastic_fwd(p, q, eps_or_z, mode, analytical_kl, Z, N):
+    """p (N|1,H,W,2Z), q (N,H,W,2Z)|None. Returns z (N,H,W,Z), logprob_p, logprob_q, kl_samplewise (N,), kl_spatial (N,H,W)."""
+    p_bcast = int(p.shape[0] == 1 and N > 1)
+    _, H, W, _ = p.shape
+    dev = p.device
+    z = torch.empty((N, H, W, Z), dtype=torch.float32, device=dev)
+    small = torch.empty((3, N), dtype=torch.float32, device=dev)
+    ks = torch.empty((N, H, W), dtype=torch.float32, device=dev) if q is not None else None
+    call('lvae_normal_stochastic_fwd_f32', ptr(p), p_bcast, ptr(q), ptr(eps_or_z), N, H * W, Z, mode, int(bool(analytical_kl)),
+         ptr(z), ptr(small[0]), ptr(small[1]) if q is not None else None, ptr(small[2]) if q is not None else None, ptr(ks),
+         stream_ptr())
+    if q is None:
+        return z, small[0], None, None, None
+    return z, small[0], small[1], small[2], ks
+
+
+def normal_stochastic_bwd(p, q, eps, z, dz, g_lp, g_lq, g_kl, g_ks, mode, analytical_kl, Z):
+    N, H, W, _ = z.shape
+    p_bcast = int(p.shape[0] == 1 and N > 1)
+    dp = torch.empty((N, H, W, 2 * Z), dtype=torch.float32, device=z.device)
+    dq = torch.empty_like(dp) if q is not None else None
+    call('lvae_normal_stochastic_bwd_f32', ptr(p), p_bcast, ptr(q), ptr(eps), ptr(z), ptr(dz), ptr(g_lp), ptr(g_lq),
+         ptr(g_kl), ptr(g_ks), N, H * W, Z, mode, int(bool(analytical_kl)), ptr(dp), ptr(dq), stream_ptr())
+    return dp, dq
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def bernoulli_fwd(logits, x, u, need_grad):
+    """logits, x, u: (N,H,W,C) NHWC. Returns mean, mode, sample, ll (N,) | None, dll_dlogits | None."""
+    N = logits.shape[0]
+    P = logits.numel() // N
+    mean, mode, sample = torch.empty_like(logits), torch.empty_like(logits), torch.empty_like(logits)
+    ll = torch.empty((N,), dtype=torch.float32, device=logits.device) if x is not None else None
+    dll = torch.empty_like(logits) if (need_grad and x is not None) else None
+    call('lvae_bernoulli_fwd_f32', ptr(logits), ptr(x), ptr(u), N, P, ptr(mean), ptr(mode), ptr(sample), ptr(ll), ptr(dll),
+         stream_ptr())
+    return mean, mode, sample, ll, dll
+
+
+def dmol_ll_fwd(l, x, need_grad):
+    """l (N,H,W,100), x (N,H,W,3) in [0,1]. Returns ll (N,), dll_dl | None."""
+    N, H, W, Cp = l.shape
+    ll = torch.empty((N,), dtype=torch.float32, device=l.device)
+    dl = torch.empty_like(l) if need_grad else None
+    need = _C.load().lvae_dmol_workspace(N, H * W)
+    ws = workspace(need, l.device)
+    call('lvae_dmol_ll_fwd_f32', ptr(l), ptr(x), N, H * W, Cp // 10, ptr(ll), ptr(dl), ws.data_ptr(), ws.numel(), stream_ptr())
+    return ll, dl
+
+
+def dmol_sample(l, u_mix, u_log):
+    N, H, W, Cp = l.shape
+    s = torch.empty((N, H, W, 3), dtype=torch.float32, device=l.device)
+    call('lvae_dmol_sample_f32', ptr(l), ptr(u_mix), ptr(u_log), N, H * W, Cp // 10, ptr(s), stream_ptr())
+    return s
+
+
+def scale_per_sample(a, g):
+    N = a.shape[0]
+    out = torch.empty_like(a)
+    call('lvae_scale_per_sample_f32', ptr(a), ptr(g), N, a.numel() // N, ptr(out), stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def upsample2x_fwd(x):
+    N, H, W, Cn = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, Cn), dtype=torch.float32, device=x.device)
+    call('lvae_upsample2x_fwd_f32', ptr(x), N, H, W, Cn, ptr(y), stream_ptr())
+    return y
+
+
+def upsample2x_bwd(dy):
+    N, H2, W2, Cn = dy.shape
+    dx = torch.empty((N, H2 // 2, W2 // 2, Cn), dtype=torch.float32, device=dy.device)
+    call('lvae_upsample2x_bwd_f32', ptr(dy), N, H2 // 2, W2 // 2, Cn, ptr(dx), stream_ptr())
+    return dx
+
+
+def pad_crop(x, src_nchw, out_hw, dst_nchw):
+    """Centred zero-pad or centre-crop + layout change. x is (N,C,H,W) contiguous when src_nchw else (N,H,W,C)."""
+    if src_nchw:
+        N, Cn, H, W = x.shape
+    else:
+        N, H, W, Cn = x.shape
+    OH, OW = int(out_hw[0]), int(out_hw[1])
+    shape = (N, Cn, OH, OW) if dst_nchw else (N, OH, OW, Cn)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    call('lvae_pad_crop_f32', ptr(x), N, Cn, H, W, int(src_nchw), ptr(y), OH, OW, int(dst_nchw), stream_ptr())
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def kl_bookkeeping_fwd(kl_ln, free_bits):
+    L, N = kl_ln.shape
+    dev = kl_ln.device
+    kl_sep = torch.empty((N,), dtype=torch.float32, device=dev)
+    kl_avg = torch.empty((L,), dtype=torch.float32, device=dev)
+    scal = torch.empty((2,), dtype=torch.float32, device=dev)
+    call('lvae_kl_bookkeeping_fwd_f32', ptr(kl_ln), L, N, float(free_bits), ptr(kl_sep), ptr(kl_avg), ptr(scal), stream_ptr())
+    return kl_sep, kl_avg, scal
+
+
+def kl_bookkeeping_bwd(kl_ln, free_bits, g_sep, g_avg, g_scal):
+    L, N = kl_ln.shape
+    dkl = torch.empty_like(kl_ln)
+    call('lvae_kl_bookkeeping_bwd_f32', ptr(kl_ln), L, N, float(free_bits), ptr(g_sep), ptr(g_avg), ptr(g_scal), ptr(dkl),
+         stream_ptr())
+    return dkl
+
+
+def elbo_loss_fwd(ll, kl_sep, kl_loss, beta):
+    N = ll.numel()
+    elbo_sep = torch.empty((N,), dtype=torch.float32, device=ll.device)
+    scal = torch.empty((3,), dtype=torch.float32, device=ll.device)
+    call('lvae_elbo_loss_fwd_f32', ptr(ll), ptr(kl_sep), ptr(kl_loss), float(beta), N, ptr(elbo_sep), ptr(scal), stream_ptr())
+    return elbo_sep, scal
+
+
+def elbo_loss_bwd(g_loss, beta, N):
+    d_ll = torch.empty((N,), dtype=torch.float32, device=g_loss.device)
+    d_kl = torch.empty((1,), dtype=torch.float32, device=g_loss.device)
+    call('lvae_elbo_loss_bwd_f32', ptr(g_loss), float(beta), N, ptr(d_ll), ptr(d_kl), stream_ptr())
+    return d_ll, d_kl
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def adamax_step(p, g, exp_avg, exp_inf, mask, lr, beta1, beta2, eps, weight_decay, gscale, step_count):
+    call('lvae_adamax_step_f32', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_inf), ptr(mask), p.numel(), lr, beta1, beta2, eps,
+         weight_decay, ptr(gscale), step_count.data_ptr(), stream_ptr())
+
+
+def l2norm(x, out=None):
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    need = _C.load().lvae_sumsq_workspace(x.numel())
+    ws = workspace(need, x.device)
+    call('lvae_l2norm_f32', ptr(x), x.numel(), ptr(out), ws.data_ptr(), ws.numel(), stream_ptr())
+    return out
+
+
+def rng_fill(out, kind, lo, hi, seed, offset, stream_id):
+    """kind: 'normal' | 'uniform' | 'bernoulli' (keep-prob lo, kept value hi). offset: device int64[1] step counter."""
+    k = {'normal': 0, 'uniform': 1, 'bernoulli': 2}[kind]
+    call('lvae_rng_fill_f32', ptr(out), out.numel(), k, float(lo), float(hi), int(seed) & (2 ** 64 - 1),
+         offset.data_ptr() if offset is not None else None, int(stream_id), stream_ptr())
+    return out
+
+
+def counter_advance(counter, by=1):
+    call('lvae_counter_advance', counter.data_ptr(), int(by), stream_ptr())

@@ -1,0 +1,80 @@
+"""Noise sources for the stochastic ops of the hot path (Dropout2d masks, reparameterisation eps, likelihood
+sample uniforms).
+
+* `PhiloxNoise` — product path: on-device Philox4x32-10 (lvae_rng_fill_f32). A device-resident step counter is
+  advanced once per forward by a plain kernel launch, so a captured hipGraph draws fresh numbers on each replay.
+* `TapeNoise` — parity path: replays a recorded tape of the reference's draws, converting each
+  entry to the NHWC / (N,C) layout the kernels read. On-device Philox cannot reproduce the CPU generator.
+"""
+import torch
+
+from . import kernels as K
+
+
+class PhiloxNoise:
+    def __init__(self, seed=0, rank=0):
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
+        self.step = None
+        self.site = 0
+
+    def begin(self, device):
+        if self.step is None or self.step.device != device:
+            self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        self.site = 0
+
+    def end(self):
+        K.counter_advance(self.step, 1)
+
+    def _fill(self, shape, kind, lo, hi, device):
+        self.site += 1
+        return K.rng_fill(torch.empty(shape, dtype=torch.float32, device=device), kind, lo, hi, self.seed, self.step,
+                          self.site)
+
+    def dropout_mask(self, N, C, p, device):
+        return self._fill((N, C), 'bernoulli', 1.0 - p, 1.0 / (1.0 - p), device)
+
+    def normal(self, shape_nhwc, device):
+        return self._fill(shape_nhwc, 'normal', 0.0, 0.0, device)
+
+    def uniform(self, shape, lo, hi, device, channel_last=True):
+        return self._fill(shape, 'uniform', lo, hi, device)
+
+
+class TapeNoise:
+    """entries: the reference's draws in call order, in the reference's own shapes (NCHW / (B,C,1,1) / channel-last)."""
+
+    def __init__(self, entries):
+        self.entries = [torch.as_tensor(e).float() for e in entries]
+        self.pos = 0
+
+    def begin(self, device):
+        pass
+
+    def end(self):
+        pass
+
+    def _next(self, shape):
+        if self.pos >= len(self.entries):
+            raise RuntimeError("noise tape exhausted at draw #%d" % self.pos)
+        t = self.entries[self.pos]
+        self.pos += 1
+        if tuple(t.shape) != tuple(shape):
+            raise RuntimeError("noise tape entry %d has shape %s, expected %s" % (self.pos - 1, tuple(t.shape), tuple(shape)))
+        return t
+
+    def exhausted(self):
+        return self.pos == len(self.entries)
+
+    def dropout_mask(self, N, C, p, device):
+        keep = self._next((N, C, 1, 1)).view(N, C)
+        return (keep / (1.0 - p)).contiguous().to(device)
+
+    def normal(self, shape_nhwc, device):
+        N, H, W, Cn = shape_nhwc
+        return self._next((N, Cn, H, W)).permute(0, 2, 3, 1).contiguous().to(device)
+
+    def uniform(self, shape, lo, hi, device, channel_last=True):
+        if channel_last:
+            return self._next(shape).contiguous().to(device)
+        N, H, W, Cn = shape
+        return self._next((N, Cn, H, W)).permute(0, 2, 3, 1).contiguous().to(device)

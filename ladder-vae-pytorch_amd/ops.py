@@ -1,0 +1,356 @@
+"""Autograd glue: torch.autograd.Function wrappers whose forward AND backward are hand-written HIP launches.
+
+torch's autograd engine is used only to order the backward calls (plumbing). Parameter gradients are written by
+the wgrad / reduction kernels straight into `param.grad` (a view of the flat gradient arena, see arena.py), so the
+Functions return None for parameter inputs; activations flow through autograd normally.
+
+All activations are NHWC (N,H,W,C) contiguous float32 CUDA tensors.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+_const_cache = {}
+
+
+def _ones_zeros(C, device):
+    key = (C, device)
+    if key not in _const_cache:
+        _const_cache[key] = (torch.ones(C, device=device), torch.zeros(C, device=device))
+    return _const_cache[key]
+
+
+def grad_buf(p):
+    """The accumulation buffer of a parameter (a view of the gradient arena once the model is packed)."""
+    if not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)  # preserve_format keeps the arena strides
+    return p.grad
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class ConvFn(Function):
+    """y = out_act(conv(cat(x, x2)) + bias); call sites: stem, pre_conv (strided / transposed), merge 1x1,
+    stochastic convs, likelihood head. `mod` is the parameter holder (lib.nn.Conv2dParams)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, mod, out_act, weight, bias):
+        g = mod.geom()
+        y = K.conv2d(x, weight, g, bias=bias, x2=x2, out_act=out_act)
+        ctx.mod, ctx.out_act, ctx.g = mod, out_act, g
+        ctx.has_x2 = x2 is not None
+        ctx.save_for_backward(x, x2, y if out_act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, y = ctx.saved_tensors
+        mod, g = ctx.mod, ctx.g
+        dy = _c(dy)
+        if ctx.out_act:
+            dy = K.act_bwd_from_out(dy, y, ctx.out_act)
+        w = mod.weight
+        if w.requires_grad:
+            K.conv2d_wgrad(x, dy, w, g, grad_buf(w), grad_buf(mod.bias) if mod.bias is not None else None, x2=x2)
+        dx = dx2 = None
+        hw = (x.shape[1], x.shape[2])
+        if x2 is None:
+            if ctx.needs_input_grad[0]:
+                dx = K.conv2d_dgrad(dy, w, g, hw)
+        else:
+            C1 = x.shape[3]
+            if ctx.needs_input_grad[0]:
+                dx = K.conv2d_dgrad(dy, w, g, hw, ci_range=(0, C1))
+            if ctx.needs_input_grad[1]:
+                dx2 = K.conv2d_dgrad(dy, w, g, hw, ci_range=(C1, g.Cin))
+        return dx, dx2, None, None, None, None
+
+
+def conv(x, mod, x2=None, out_act=None):
+    return ConvFn.apply(x, x2, mod, out_act, mod.weight, mod.bias)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class ResBlockFn(Function):
+    """Whole pre-activation residual block ('bacdbacd' / 'bacdbac' recipes of lib/nn.py:64-89, with or without
+    BatchNorm, Dropout2d and the gate) as ONE autograd node:
+
+        y1 = drop1(conv1(act(bn1(x))))   -> one conv launch (BN-apply+act fused in the A-operand load, bias + dropout
+        y2 = drop2(conv2(act(bn2(y1))))     scale in the epilogue) + one statistics pass per BN
+        out = gate(conv1x1(y2)) + x      or  y2 + x
+
+    Saved for backward: x, y1, y2, ab and the BN coefficients; act(bn(.)) is recomputed inside the wgrad loader.
+    """
+
+    @staticmethod
+    def forward(ctx, x, blk, m1, m2, training, *params):
+        act = blk.act
+        dev = x.device
+        C = x.shape[3]
+        st = []
+        h = x
+        for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
+            if bn is not None:
+                if training:
+                    sc, sh, mean, rstd = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                                    bn.momentum)
+                else:
+                    sc, sh = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+                    mean = rstd = None
+            else:
+                sc, sh = _ones_zeros(C, dev)
+                mean = rstd = None
+            y = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m)
+            st.append((h, sc, sh, mean, rstd))
+            h = y
+        y2 = h
+        ab = None
+        if blk.gate is not None:
+            ab = K.conv2d(y2, blk.gate.weight, blk.gate.geom(), bias=blk.gate.bias)
+            out = K.gate_fwd(ab, x, act)
+        else:
+            out = K.add(y2, x)
+        ctx.blk, ctx.training = blk, training
+        (x0, sc1, sh1, mean1, rstd1), (y1, sc2, sh2, mean2, rstd2) = st
+        ctx.save_for_backward(x0, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        act = blk.act
+        x, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2 = ctx.saved_tensors
+        dout = _c(dout)
+        hw = (x.shape[1], x.shape[2])
+        if blk.gate is not None:
+            gw = blk.gate.weight
+            dab = K.gate_bwd(dout, ab, act)
+            K.conv2d_wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
+            dy2 = K.conv2d_dgrad(dab, gw, blk.gate.geom(), hw, out_scale=m2)
+        else:
+            dy2 = K.scale_rows_add(dout, m2, None) if m2 is not None else dout
+        # second half
+        w2 = blk.conv2.weight
+        K.conv2d_wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2,
+                       in_act=act)
+        dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
+        bn2 = blk.bn2
+        train2 = bn2 is not None and ctx.training
+        dy1 = K.affine_act_bwd(dh2, y1, sc2, sh2, act, train2, mean2, rstd2,
+                               grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
+        # first half
+        w1 = blk.conv1.weight
+        K.conv2d_wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1,
+                       in_act=act)
+        dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
+        bn1 = blk.bn1
+        train1 = bn1 is not None and ctx.training
+        dx = K.affine_act_bwd(dh1, x, sc1, sh1, act, train1, mean1, rstd1,
+                              grad_buf(bn1.weight) if train1 else None, grad_buf(bn1.bias) if train1 else None, add=dout)
+        return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# small nodes used by the non-fused 'cabdcabd' recipe (lib/nn.py:50-62)
+class BnDropFn(Function):
+    """y = BN(x) * mask[n, c] materialised (BatchNorm after the activation, then Dropout2d)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, mask, training, *params):
+        if bn is not None:
+            if training:
+                sc, sh, mean, rstd = K.bn_stats(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            else:
+                sc, sh = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+                mean = rstd = None
+        else:
+            sc, sh = _ones_zeros(x.shape[3], x.device)
+            mean = rstd = None
+        y = K.affine_act(x, sc, sh, None, row_scale=mask)
+        ctx.bn, ctx.training = bn, training
+        ctx.save_for_backward(x, sc, sh, mean, rstd, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sc, sh, mean, rstd, mask = ctx.saved_tensors
+        dy = _c(dy)
+        if mask is not None:
+            dy = K.scale_rows_add(dy, mask, None)
+        bn = ctx.bn
+        train = bn is not None and ctx.training
+        dx = K.affine_act_bwd(dy, x, sc, sh, None, train, mean, rstd, grad_buf(bn.weight) if train else None,
+                              grad_buf(bn.bias) if train else None)
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class GateFn(Function):
+    """out = act(a) * sigmoid(b) [+ res] from ab = conv1x1 output (lib/nn.py:121-126)."""
+
+    @staticmethod
+    def forward(ctx, ab, res, act):
+        ctx.act = act
+        ctx.has_res = res is not None
+        ctx.save_for_backward(ab)
+        return K.gate_fwd(ab, res, act)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ab,) = ctx.saved_tensors
+        dout = _c(dout)
+        return K.gate_bwd(dout, ab, ctx.act), (dout if ctx.has_res else None), None
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class NormalStochFn(Function):
+    """lib/stochastic.py:45-99 elementwise core. Returns z, logprob_p, logprob_q, kl_samplewise, kl_spatial."""
+
+    @staticmethod
+    def forward(ctx, p, q, noise, mode, analytical, Z, N):
+        z, lp, lq, kl, ks = K.normal_stochastic_fwd(p, q, noise, mode, analytical, Z, N)
+        ctx.mode, ctx.analytical, ctx.Z = mode, analytical, Z
+        ctx.has_q = q is not None
+        ctx.p_bcast = p.shape[0] == 1 and N > 1
+        ctx.save_for_backward(p, q, noise if mode == 0 else None, z)
+        if q is None:
+            return z, lp
+        return z, lp, lq, kl, ks
+
+    @staticmethod
+    def backward(ctx, dz, g_lp, g_lq=None, g_kl=None, g_ks=None):
+        p, q, eps, z = ctx.saved_tensors
+        cc = lambda t: None if t is None else _c(t)
+        dp, dq = K.normal_stochastic_bwd(p, q, eps, z, cc(dz), cc(g_lp), cc(g_lq), cc(g_kl), cc(g_ks), ctx.mode,
+                                         ctx.analytical, ctx.Z)
+        if ctx.p_bcast:
+            red = torch.empty_like(p)
+            K.colsum(dp.view(dp.shape[0], -1), red.view(-1), False)
+            dp = red
+        return dp, dq, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class BernoulliFn(Function):
+    """lib/likelihoods.py:60-78: returns ll (N,) [differentiable], mean, mode, sample (NHWC, no grad)."""
+
+    @staticmethod
+    def forward(ctx, logits, x, u):
+        mean, mode, sample, ll, dll = K.bernoulli_fwd(logits, x, u, True)
+        ctx.save_for_backward(dll)
+        ctx.mark_non_differentiable(mode, sample)
+        ctx.has_ll = ll is not None
+        if ll is None:
+            ll = torch.zeros((logits.shape[0],), device=logits.device)
+        return ll, mean, mode, sample
+
+    @staticmethod
+    def backward(ctx, g_ll, g_mean, g_mode, g_sample):
+        (dll,) = ctx.saved_tensors
+        if dll is None:
+            return None, None, None
+        return K.scale_per_sample(dll, _c(g_ll)), None, None
+
+
+class DmolFn(Function):
+    """lib/likelihoods.py:227-230 + 291-382: ll (N,) from params (N,H,W,100) and x (N,H,W,3) in [0,1]."""
+
+    @staticmethod
+    def forward(ctx, l, x):
+        ll, dl = K.dmol_ll_fwd(l, x, True)
+        ctx.save_for_backward(dl)
+        return ll
+
+    @staticmethod
+    def backward(ctx, g_ll):
+        (dl,) = ctx.saved_tensors
+        return K.scale_per_sample(dl, _c(g_ll)), None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class UpsampleFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return K.upsample2x_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.upsample2x_bwd(_c(dy))
+
+
+class CropFn(Function):
+    """centre crop (or pad) of an NHWC tensor; backward is the inverse pad (or crop)."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return K.pad_crop(x, False, out_hw, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.pad_crop(_c(dy), False, ctx.in_hw, False), None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class KLBookFn(Function):
+    """models/lvae.py:192-198: kl (L,N) -> kl_sep (N,), kl_avg_layerwise (L,), scalars [kl_loss, kl]."""
+
+    @staticmethod
+    def forward(ctx, kl_ln, free_bits):
+        ctx.fb = free_bits
+        ctx.save_for_backward(kl_ln)
+        return K.kl_bookkeeping_fwd(kl_ln, free_bits)
+
+    @staticmethod
+    def backward(ctx, g_sep, g_avg, g_scal):
+        (kl_ln,) = ctx.saved_tensors
+        cc = lambda t: None if t is None else _c(t)
+        return K.kl_bookkeeping_bwd(kl_ln, ctx.fb, cc(g_sep), cc(g_avg), cc(g_scal)), None
+
+
+class StackFn(Function):
+    """stack L per-layer (N,) vectors into one (L,N) matrix; backward hands the rows back as views."""
+
+    @staticmethod
+    def forward(ctx, *rows):
+        out = torch.empty((len(rows), rows[0].numel()), dtype=torch.float32, device=rows[0].device)
+        for i, r in enumerate(rows):
+            K.scale_rows_add(_c(r).view(1, -1), None, None, out=out[i])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return tuple(g[i] for i in range(g.shape[0]))
+
+
+class ElboLossFn(Function):
+    """experiment/experiment_manager.py:329-344: returns elbo_sep (N,), scalars [loss, elbo, recons]."""
+
+    @staticmethod
+    def forward(ctx, ll, kl_sep, kl_loss, beta):
+        ctx.beta, ctx.N = beta, ll.numel()
+        elbo_sep, scal = K.elbo_loss_fwd(ll, kl_sep, kl_loss, beta)
+        ctx.mark_non_differentiable(elbo_sep)
+        return elbo_sep, scal
+
+    @staticmethod
+    def backward(ctx, g_sep, g_scal):
+        # only d(loss) is propagated; elbo / recons are metrics
+        d_ll, d_kl = K.elbo_loss_bwd(_c(g_scal)[0:1], ctx.beta, ctx.N)
+        return d_ll, None, d_kl, None

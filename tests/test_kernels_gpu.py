@@ -1,0 +1,298 @@
+"""Per-kernel parity on the GPU: each C-ABI entry point against a plain PyTorch fp32 CPU op of the same maths."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    import lvae_amd  # noqa: F401
+    from lvae_amd import kernels
+    return kernels
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def packed_weight(w, transposed=False):
+    """the arena layout: physical [KH][KW][Cin][Cout], logical torch shape"""
+    if transposed:  # (Cin,Cout,KH,KW)
+        return w.permute(2, 3, 0, 1).contiguous().cuda().permute(2, 3, 0, 1)
+    return w.permute(2, 3, 1, 0).contiguous().cuda().permute(3, 2, 0, 1)
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, k, stride, pad
+    (4, 64, 64, 16, 16, 3, 1, 1),
+    (3, 64, 128, 8, 8, 1, 1, 0),
+    (2, 32, 64, 4, 4, 3, 1, 1),
+    (5, 64, 64, 16, 16, 3, 2, 1),
+    (3, 3, 64, 32, 32, 5, 2, 2),
+    (2, 1, 16, 28, 28, 5, 2, 2),
+    (2, 64, 100, 32, 32, 3, 1, 1),
+    (3, 64, 1, 28, 28, 3, 1, 1),
+    (2, 16, 6, 16, 16, 3, 1, 1),
+    (70, 64, 64, 16, 16, 3, 1, 1),   # > 128 tiles: BM = 128 path
+    (40, 64, 128, 16, 16, 1, 1, 0),  # BM = 128, BN = 128
+    (2, 8, 8, 2, 2, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(K, case):
+    N, Ci, Co, H, W, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=g)
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = packed_weight(w.detach())
+    geom = K.ConvGeom(wp, stride=s, pad=p)
+    yd = K.conv2d(nhwc(x.detach()), wp, geom, bias=b.detach().cuda())
+    assert rel(nchw(yd), y.detach()) < 2e-6
+    dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W))
+    assert rel(nchw(dx), x.grad) < 2e-6
+    dw = torch.zeros_like(wp)
+    db = torch.zeros(Co, device='cuda')
+    K.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), wp, geom, dw, db)
+    assert rel(dw.cpu(), w.grad) < 3e-6
+    assert rel(db.cpu(), b.grad) < 3e-6
+    # accumulate semantics
+    K.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), wp, geom, dw, db)
+    assert rel(dw.cpu(), 2 * w.grad) < 3e-6
+    # default (Cout,Cin,KH,KW)-contiguous layout goes through the scalar weight path
+    wc = w.detach().cuda().contiguous()
+    yd2 = K.conv2d(nhwc(x.detach()), wc, K.ConvGeom(wc, stride=s, pad=p), bias=b.detach().cuda())
+    assert rel(nchw(yd2), y.detach()) < 2e-6
+
+
+@pytest.mark.parametrize('case', [(3, 64, 64, 4, 4), (2, 16, 8, 8, 8), (40, 64, 64, 8, 8)])
+def test_conv_transpose(K, case):
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Ci, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Ci, Co, 3, 3, generator=g) / math.sqrt(Ci * 9)).requires_grad_(True)
+    b = torch.randn(Co, generator=g, requires_grad=True)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = packed_weight(w.detach(), transposed=True)
+    geom = K.ConvGeom(wp, stride=2, pad=1, transposed=True, output_padding=1)
+    yd = K.conv2d(nhwc(x.detach()), wp, geom, bias=b.detach().cuda())
+    assert tuple(yd.shape) == (N, 2 * H, 2 * W, Co)
+    assert rel(nchw(yd), y.detach()) < 2e-6
+    assert rel(nchw(K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W))), x.grad) < 2e-6
+    dw, db = torch.zeros_like(wp), torch.zeros(Co, device='cuda')
+    K.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), wp, geom, dw, db)
+    assert rel(dw.cpu(), w.grad) < 3e-6 and rel(db.cpu(), b.grad) < 3e-6
+
+
+def test_conv_fused_prologue_epilogue_and_cat(K):
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 6, 64, 8, 8
+    x1, x2 = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(2 * C, generator=g) + 0.5, torch.randn(2 * C, generator=g)
+    w = torch.randn(C, 2 * C, 3, 3, generator=g) / 30
+    b = torch.randn(C, generator=g)
+    drop = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
+    xin = F.elu(torch.cat((x1, x2), 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.elu(F.conv2d(xin, wr, b, padding=1) * drop.view(N, C, 1, 1))
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    yd = K.conv2d(nhwc(x1), wp, geom, bias=b.cuda(), x2=nhwc(x2), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
+                  out_scale=drop.cuda(), out_act='elu')
+    assert rel(nchw(yd), y.detach()) < 2e-6
+    dy = torch.randn(y.shape, generator=g)
+    pre = F.conv2d(xin, wr, b, padding=1)
+    pre.backward(dy)
+    dw = torch.zeros_like(wp)
+    K.conv2d_wgrad(nhwc(x1), nhwc(dy), wp, geom, dw, None, x2=nhwc(x2), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu')
+    assert rel(dw.cpu(), wr.grad) < 3e-6
+    dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W))
+    assert rel(nchw(dx), xin.grad) < 2e-6
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 16, 16), (3, 8, 5, 7), (4, 3, 6, 6), (64, 64, 32, 32)])
+def test_bn_stats_and_affine_bwd(K, shape):
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 2 + 3).requires_grad_(True)   # large mean: exercises the pivoted variance
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    h = F.elu(F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    dh = torch.randn(shape, generator=g)
+    h.backward(dh)
+    xd = nhwc(x.detach())
+    rmd, rvd = rm.cuda(), rv.cuda()
+    sc, sh, mean, rstd = K.bn_stats(xd, gamma.detach().cuda(), beta.detach().cuda(), rmd, rvd)
+    torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    hd = K.affine_act(xd, sc, sh, 'elu')
+    assert rel(nchw(hd), h.detach()) < 2e-6
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dx = K.affine_act_bwd(nhwc(dh), xd, sc, sh, 'elu', True, mean, rstd, dg, db)
+    assert rel(nchw(dx), x.grad) < 1e-5
+    assert rel(dg.cpu(), gamma.grad) < 1e-5 and rel(db.cpu(), beta.grad) < 1e-5
+
+
+def test_gate(K):
+    g = torch.Generator().manual_seed(6)
+    ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
+    res = torch.randn(5, 64, 4, 4, generator=g)
+    a, b = ab.chunk(2, 1)
+    out = F.elu(a) * torch.sigmoid(b) + res
+    do = torch.randn(out.shape, generator=g)
+    out.backward(do)
+    abd = nhwc(ab.detach())
+    assert rel(nchw(K.gate_fwd(abd, nhwc(res), 'elu')), out.detach()) < 1e-6
+    assert rel(nchw(K.gate_bwd(nhwc(do), abd, 'elu')), ab.grad) < 1e-6
+
+
+@pytest.mark.parametrize('analytical', [False, True])
+@pytest.mark.parametrize('top', [False, True])
+def test_normal_stochastic(K, analytical, top):
+    from oracle import lvae_ref as R
+    g = torch.Generator().manual_seed(8)
+    N, Z, H, W = 6, 32, 4, 4
+    p = (torch.randn(1 if top else N, 2 * Z, H, W, generator=g) * 0.5).requires_grad_(True)
+    q = (torch.randn(N, 2 * Z, H, W, generator=g) * 0.5).requires_grad_(True)
+    eps = torch.randn(N, Z, H, W, generator=g)
+    pmu, plv = p.chunk(2, 1)
+    qmu, qlv = q.chunk(2, 1)
+    z = qmu + (qlv / 2).exp() * eps
+    lp = R.normal_log_prob(z, pmu, plv).sum((1, 2, 3))
+    lq = R.normal_log_prob(z, qmu, qlv).sum((1, 2, 3))
+    kan = R.normal_kl(qmu, qlv, pmu, plv)
+    kl = kan.sum((1, 2, 3)) if analytical else (R.normal_log_prob(z, qmu, qlv) - R.normal_log_prob(z, pmu, plv)).sum((1, 2, 3))
+    ks = kan.sum(1)
+    dz, glp, glq, gkl, gks = (torch.randn(z.shape, generator=g), torch.randn(N, generator=g), torch.randn(N, generator=g),
+                              torch.randn(N, generator=g), torch.randn(ks.shape, generator=g))
+    ((z * dz).sum() + (lp * glp).sum() + (lq * glq).sum() + (kl * gkl).sum() + (ks * gks).sum()).backward()
+    pd, qd, ed = nhwc(p.detach()), nhwc(q.detach()), nhwc(eps)
+    zd, lpd, lqd, kld, ksd = K.normal_stochastic_fwd(pd, qd, ed, 0, analytical, Z, N)
+    torch.testing.assert_close(nchw(zd), z.detach(), rtol=1e-5, atol=1e-5)
+    for a, b in ((lpd, lp), (lqd, lq), (kld, kl)):
+        torch.testing.assert_close(a.cpu(), b.detach(), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(ksd.cpu(), ks.detach(), rtol=1e-5, atol=1e-4)
+    dp, dq = K.normal_stochastic_bwd(pd, qd, ed, zd, nhwc(dz), glp.cuda(), glq.cuda(), gkl.cuda(), gks.cuda(), 0, analytical, Z)
+    dpc = nchw(dp).sum(0, keepdim=True) if top else nchw(dp)
+    assert rel(dpc, p.grad) < 1e-5 and rel(nchw(dq), q.grad) < 1e-5
+
+
+def test_likelihood_golden_vectors(K):
+    from conftest import load_golden
+    g = load_golden('ops')
+    mean, xb = g.t('bern.mean'), g.t('bern.x')
+    logits = torch.log(mean.clamp(1e-30)) - torch.log1p(-mean.clamp(max=1 - 1e-7))
+    # Bernoulli: compare through logits that reproduce the (unsaturated) means; saturation is tested below
+    m, mode, smp, ll, dll = K.bernoulli_fwd(nhwc(logits), nhwc(xb), nhwc(torch.rand_like(xb)), True)
+    keep = (mean > 1e-6) & (mean < 1 - 1e-6)
+    torch.testing.assert_close(nchw(m)[keep], mean[keep], rtol=1e-5, atol=1e-6)
+    big = torch.tensor([[40., -40., 200., -200.]]).view(1, 1, 2, 2)
+    xs = torch.tensor([[0., 1., 0., 1.]]).view(1, 1, 2, 2)
+    _, _, _, ll_s, _ = K.bernoulli_fwd(nhwc(big), nhwc(xs), nhwc(torch.rand_like(xs)), False)
+    ref = -F.binary_cross_entropy(torch.sigmoid(big), xs, reduction='none').sum()
+    torch.testing.assert_close(ll_s.cpu()[0], ref, rtol=1e-6, atol=1e-4)
+    assert float(ref) < -150
+    # DMoL log-likelihood, gradient and sampler against the reference's outputs
+    l, xd = g.t('dmol.l'), g.t('dmol.x')
+    ll, dl = K.dmol_ll_fwd(nhwc(l), nhwc(xd), True)
+    torch.testing.assert_close(ll.cpu(), g.t('dmol.ll'), rtol=1e-5, atol=1e-3)
+    # the stress vector sits where cdf_delta ~ 1e-5: the reference's own fp32 gradient is only good to ~1e-2 there
+    torch.testing.assert_close(nchw(dl), g.t('dmol.dl'), rtol=1e-2, atol=2e-3)
+    tape = g.seq('dmol.tape')
+    s = K.dmol_sample(nhwc(l), tape[0].cuda().contiguous(), tape[1].cuda().contiguous())
+    torch.testing.assert_close(nchw(s) * 2 - 1, g.t('dmol.sample'), rtol=1e-5, atol=1e-5)
+
+
+def test_upsample_pad_crop(K):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 8, 5, 6, generator=g, requires_grad=True)
+    y = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    assert rel(nchw(K.upsample2x_fwd(nhwc(x.detach()))), y.detach()) < 1e-6
+    assert rel(nchw(K.upsample2x_bwd(nhwc(dy))), x.grad) < 1e-6
+    from oracle import lvae_ref as R
+    xi = torch.randn(2, 3, 28, 27, generator=g)
+    pad = K.pad_crop(xi.cuda(), True, (32, 32), False)
+    torch.testing.assert_close(nchw(pad), R.pad_img_tensor(xi, (32, 32)))
+    crop = K.pad_crop(pad, False, (28, 27), True)
+    torch.testing.assert_close(crop.cpu(), xi)
+
+
+def test_kl_bookkeeping_elbo_adamax_l2(K):
+    from oracle import lvae_ref as R
+    g = torch.Generator().manual_seed(10)
+    L, N = 5, 37
+    kl = (torch.rand(N, L, generator=g) * 2).requires_grad_(True)
+    ll = (-torch.rand(N, generator=g) * 100).requires_grad_(True)
+    for fb in (0.0, 0.7):
+        kl.grad = ll.grad = None
+        kl_loss = R.free_bits_kl(kl, fb).sum()
+        kl_sep = kl.sum(1)
+        loss = (-ll).mean() + 0.3 * kl_loss
+        (loss * 1.7).backward()
+        kl_ln = kl.detach().t().contiguous().cuda()
+        ksep, kavg, scal = K.kl_bookkeeping_fwd(kl_ln, fb)
+        torch.testing.assert_close(ksep.cpu(), kl_sep.detach())
+        torch.testing.assert_close(kavg.cpu(), kl.detach().mean(0))
+        torch.testing.assert_close(scal.cpu(), torch.stack((kl_loss.detach(), kl_sep.detach().mean())))
+        esep, s3 = K.elbo_loss_fwd(ll.detach().cuda(), ksep, scal[0:1], 0.3)
+        torch.testing.assert_close(s3.cpu()[0], loss.detach())
+        torch.testing.assert_close(esep.cpu(), (ll - kl_sep).detach())
+        d_ll, d_kll = K.elbo_loss_bwd(torch.tensor([1.7], device='cuda'), 0.3, N)
+        torch.testing.assert_close(d_ll.cpu(), ll.grad)
+        gs = torch.cat((d_kll, torch.zeros(1, device='cuda')))
+        dkl = K.kl_bookkeeping_bwd(kl_ln, fb, None, None, gs)
+        torch.testing.assert_close(dkl.t().cpu(), kl.grad)
+    # Adamax against torch.optim.Adamax, three steps
+    n = 1000
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adamax([pr], lr=3e-4)
+    pd, m, u = p0.cuda(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    step = torch.zeros(1, dtype=torch.int64, device='cuda')
+    for gr in grads:
+        pr.grad = gr.clone()
+        opt.step()
+        K.adamax_step(pd, gr.cuda(), m, u, None, 3e-4, 0.9, 0.999, 1e-8, 0.0, None, step)
+        K.counter_advance(step)
+    torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+    assert int(step.item()) == 3
+    torch.testing.assert_close(K.l2norm(pd).cpu()[0], pr.detach().norm(), rtol=1e-6, atol=0)
+
+
+def test_rng_statistics(K):
+    n = 1 << 20
+    off = torch.zeros(1, dtype=torch.int64, device='cuda')
+    a = K.rng_fill(torch.empty(n, device='cuda'), 'normal', 0, 0, 1234, off, 1)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    u = K.rng_fill(torch.empty(n, device='cuda'), 'uniform', 1e-5, 1 - 1e-5, 1234, off, 2)
+    assert 0 < float(u.min()) and float(u.max()) < 1 and abs(float(u.mean()) - 0.5) < 2e-3
+    b = K.rng_fill(torch.empty(n, device='cuda'), 'bernoulli', 0.8, 1.25, 1234, off, 3)
+    assert abs(float((b > 0).float().mean()) - 0.8) < 2e-3 and float(b.max()) == 1.25
+    a2 = K.rng_fill(torch.empty(n, device='cuda'), 'normal', 0, 0, 1234, off, 1)
+    assert torch.equal(a, a2)              # same (seed, step, call site) -> same numbers
+    K.counter_advance(off)
+    a3 = K.rng_fill(torch.empty(n, device='cuda'), 'normal', 0, 0, 1234, off, 1)
+    assert abs(float((a * a3).mean())) < 5e-3  # next step: fresh, uncorrelated
