@@ -1,0 +1,189 @@
+"""bench.py — training throughput of the LVAE hot path on MI355X (driver contract).
+
+Workload (BASELINE.json metric): one ELBO training step = forward + backward + Adamax [+ gradient all-reduce] of the
+CIFAR10-shaped 15-layer Ladder VAE (BASELINE configs[2]: fp32, batch 256 per GPU, DMoL likelihood), synthetic images,
+default init under torch.manual_seed(42). Inputs are resident in HBM before the timed region. Weak scaling: every
+rank processes its own 256-image shard; `value` = images of all ranks / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline     — fp32-MFMA roofline of the dominant kernel family (conv_igemm_kernel, forward + dgrad launches), from an
+                 instrumented eager step timed with HIP events on the launch stream (not part of `value`);
+  cpu_baseline — the CPU oracle (oracle/lvae_ref.py, a port of the reference) timed on this box's host cores on a
+                 bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CIFAR15 = dict(color_ch=3, z_dims=[32] * 15, blocks_per_layer=4, downsample=[0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0],
+               nonlin='elu', merge_type='residual', batchnorm=True, stochastic_skip=True, n_filters=64, dropout=0.2,
+               free_bits=1.0, learn_top_prior=True, img_shape=(32, 32), likelihood_form='discr_log_mix',
+               res_block_type='bacdbacd', gated=True, no_initial_downscaling=False, analytical_kl=False)
+PEAK_MFMA_F32 = 157.3  # TFLOP/s, MI355X_MICROARCH.md
+
+
+def synth_batches(n, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.floor(256 * torch.rand(batch, 3, 32, 32, generator=g)) / 255 for _ in range(n)]
+
+
+def conv_roofline(model, x):
+    """Instrumented eager step: HIP events around every lvae_conv2d_f32 launch (conv_igemm_kernel: forward and dgrad)
+    on the launch stream. Returns algorithmic FLOPs / measured time over all those launches."""
+    from lvae_amd import kernels as K
+    from lvae_amd.engine import forward_pass
+    rec = []
+    orig = K.call
+
+    def timed_call(name, *args):
+        if name != 'lvae_conv2d_f32':
+            return orig(name, *args)
+        d = args[0]._obj
+        flops = 2.0 * d.N * d.OH * d.OW * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
+        if d.gather == 1 and d.stride > 1:
+            flops /= d.stride * d.stride  # taps that hit no input pixel are not algorithmic work
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(name, *args)
+        e1.record()
+        rec.append((flops, e0, e1))
+
+    K.call = timed_call
+    try:
+        model.zero_grad()
+        out = forward_pass(model, x)
+        out['loss'].backward()
+        torch.cuda.synchronize()
+    finally:
+        K.call = orig
+    tot_f = sum(r[0] for r in rec)
+    tot_ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+    return tot_f, tot_ms, len(rec)
+
+
+def cpu_baseline(cfg, batch, steps):
+    """The oracle (CPU port of the reference path) on this box's host cores: forward + backward + Adamax."""
+    from oracle import lvae_ref as R
+    from lvae_amd.models.lvae import LadderVAE
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    sd = {k: v.clone() for k, v in LadderVAE(**cfg).state_dict().items()}
+    pkeys = [k for k in sd if R.is_parameter_key(k)]
+    for k in pkeys:
+        sd[k].requires_grad_(k != 'top_down_layers.%d.top_prior_params' % (len(cfg['z_dims']) - 1) or cfg['learn_top_prior'])
+    tk = [k for k in pkeys if sd[k].requires_grad]
+    m = [torch.zeros_like(sd[k]) for k in tk]
+    u = [torch.zeros_like(sd[k]) for k in tk]
+    xs = synth_batches(2, batch, 99)
+    gen = torch.Generator().manual_seed(1)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        for k in tk:
+            sd[k].grad = None
+        fp, _ = R.forward_pass(sd, cfg, xs[i % 2], R.Tape(gen=gen), param_keys=pkeys)
+        fp['loss'].backward()
+        with torch.no_grad():
+            R.adamax_step([sd[k] for k in tk], [sd[k].grad for k in tk], m, u, i + 1)
+        times.append(time.time() - t0)
+    t = sum(times[1:]) / steps
+    return {'value': batch / t, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': 'CIFAR-15 fp32 batch %d, fwd+bwd+Adamax, 1 warm-up + %d timed steps (%.1f s/step)' % (batch, steps, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import lvae_amd  # noqa: F401
+    from lvae_amd import dist as ldist
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import PhiloxNoise
+    from lvae_amd.optim import Adamax
+    from lvae_amd.engine import TrainStep
+
+    rank, world, local = ldist.init_from_env('nccl')
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
+                         (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    torch.manual_seed(42)  # identical default init on every rank (README's seed)
+    model = LadderVAE(**CIFAR15).to(dev)
+    model.train()
+    model.noise = PhiloxNoise(seed=42, rank=rank)
+    arena = model.pack()
+    ldist.broadcast_flat(arena.params)
+    opt = Adamax(model, lr=3e-4)
+    allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
+    step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce)
+
+    ring = [b.to(dev) for b in synth_batches(8, args.batch, 1234 + rank)]
+    for i in range(max(args.warmup, 3)):  # >= 3: two eager steps + the capture replay
+        step(ring[i % 8])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(ring[i % 8])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss, elbo = float(out['loss']), float(out['elbo'])
+
+    line = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        line = {
+            'metric': 'training images/sec (ELBO step: fwd+bwd+Adamax' + ('+grad all-reduce' if world > 1 else '') + ')',
+            'value': args.batch * world * args.steps / dt, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'CIFAR10-shaped 15-layer LVAE (BASELINE configs[2]): 32x32x3, zdims 32x15, 4 blocks/layer, '
+                                   '64 filters, gated+skip, DMoL-10, dropout 0.2, free bits 1.0',
+                       'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
+                       'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph},
+            'neg_elbo': -elbo, 'loss': loss,
+        }
+    if rank == 0 and not args.no_roofline:
+        f, ms_conv, n = conv_roofline(model, ring[0])
+        ach = f / (ms_conv * 1e-3) / 1e12
+        line['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
+                            'frac': ach / PEAK_MFMA_F32, 'traffic': None, 'kernel': 'conv_igemm_kernel (fwd+dgrad)',
+                            'launches': n, 'avg_launch_us': ms_conv * 1e3 / n, 'flops_per_step': f,
+                            'conv_ms_per_step': ms_conv}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(CIFAR15, 32, 3)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

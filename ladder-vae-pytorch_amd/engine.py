@@ -1,0 +1,95 @@
+"""Whole-step execution: forward + backward + L2 norm [+ Adamax] captured once as a hipGraph and replayed.
+
+The eager schedule of one CIFAR-15 step is several thousand dependent launches; replaying a
+captured graph removes the Python / launch overhead without a tracing compiler. RNG state lives in device memory
+and is advanced by a kernel inside the graph, so every replay draws fresh noise. With world_size > 1 the gradient
+all-reduce sits between two graphs (fwd+bwd | all-reduce on a side stream | Adamax).
+"""
+import torch
+
+from . import kernels as K
+from . import ops
+
+
+def linear_anneal(step, start, end, steps):
+    """boilr.utils.linear_anneal (absent; restated): linear ramp from start to end over `steps` steps, then flat."""
+    if steps <= 0:
+        return end
+    return start + (end - start) * min(max(step / float(steps), 0.0), 1.0)
+
+
+def forward_pass(model, x, beta=1.0, compute_l2=True):
+    """LVAEExperiment.forward_pass (experiment/experiment_manager.py:322-367) on the HIP engine."""
+    mo = model(x)
+    elbo_sep, scal = ops.ElboLossFn.apply(mo['ll'], mo['kl_sep'], mo['kl_loss'], float(beta))
+    loss, elbo, recons = scal.unbind(0)
+    out = {'loss': loss, 'elbo': elbo, 'elbo_sep': elbo_sep, 'kl': mo['kl'], 'recons': recons,
+           'out_mean': mo['out_mean'], 'out_mode': mo['out_mode'], 'out_sample': mo['out_sample'],
+           'likelihood_params': mo['likelihood_params'], 'kl_avg_layerwise': mo['kl_avg_layerwise']}
+    if compute_l2:
+        with torch.no_grad():
+            out['l2'] = K.l2norm(model.arena.params).view(())
+    return out
+
+
+class TrainStep:
+    """step(x) -> dict of scalars (device tensors, valid until the next step)."""
+
+    def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2):
+        self.model, self.opt, self.beta = model, optimizer, beta
+        self.use_graph, self.allreduce = use_graph, allreduce
+        self.eager_left = eager_warmup if use_graph else -1
+        self.graph_a = self.graph_b = None
+        self.static_x = None
+        self.static_out = None
+        self._bns = None
+        if allreduce is not None and allreduce.world > 1:
+            optimizer._state()
+            optimizer.gscale = allreduce.scale
+
+    def _fwd_bwd(self, x):
+        self.opt.zero_grad()
+        out = forward_pass(self.model, x, self.beta)
+        out['loss'].backward()
+        return {k: out[k].detach() for k in ('loss', 'elbo', 'recons', 'kl', 'l2', 'kl_avg_layerwise')}
+
+    def _eager(self, x):
+        out = self._fwd_bwd(x)
+        if self.allreduce is not None:
+            self.allreduce.run()
+        self.opt.step()
+        return out
+
+    def _capture(self, x):
+        self.static_x = torch.empty_like(x)
+        self.static_x.copy_(x)
+        fused = self.allreduce is None or self.allreduce.world == 1
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.static_out = self._fwd_bwd(self.static_x)
+            if fused:
+                self.opt.step()
+        if not fused:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self.opt.step()
+        self._bns = self.model.bn_modules()
+
+    def __call__(self, x):
+        self.model.global_step += 1
+        if not self.use_graph or self.eager_left > 0:
+            self.eager_left -= 1
+            return self._eager(x)
+        if self.graph_a is None:
+            self._capture(x)
+        else:
+            self.static_x.copy_(x, non_blocking=True)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self.allreduce.run()
+            self.graph_b.replay()
+        if self.model.training:
+            for bn in self._bns:
+                bn._pending += 1
+        return self.static_out

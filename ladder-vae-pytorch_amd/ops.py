@@ -345,6 +345,7 @@ class ElboLossFn(Function):
     @staticmethod
     def forward(ctx, ll, kl_sep, kl_loss, beta):
         ctx.beta, ctx.N = beta, ll.numel()
+        ctx.kl_dim0 = kl_loss.dim() == 0
         elbo_sep, scal = K.elbo_loss_fwd(ll, kl_sep, kl_loss, beta)
         ctx.mark_non_differentiable(elbo_sep)
         return elbo_sep, scal
@@ -353,4 +354,4 @@ class ElboLossFn(Function):
     def backward(ctx, g_sep, g_scal):
         # only d(loss) is propagated; elbo / recons are metrics
         d_ll, d_kl = K.elbo_loss_bwd(_c(g_scal)[0:1], ctx.beta, ctx.N)
-        return d_ll, None, d_kl, None
+        return d_ll, None, d_kl.view(()) if ctx.kl_dim0 else d_kl, None
