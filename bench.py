@@ -30,6 +30,19 @@ CIFAR15 = dict(color_ch=3, z_dims=[32] * 15, blocks_per_layer=4, downsample=[0, 
 PEAK_MFMA_F32 = 157.3  # TFLOP/s, MI355X_MICROARCH.md
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped at the GPU box's per-GPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
 def synth_batches(n, batch, seed):
     g = torch.Generator().manual_seed(seed)
     return [torch.floor(256 * torch.rand(batch, 3, 32, 32, generator=g)) / 255 for _ in range(n)]
@@ -73,7 +86,7 @@ def cpu_baseline(cfg, batch, steps):
     """The oracle (CPU port of the reference path) on this box's host cores: forward + backward + Adamax."""
     from oracle import lvae_ref as R
     from lvae_amd.models.lvae import LadderVAE
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     sd = {k: v.clone() for k, v in LadderVAE(**cfg).state_dict().items()}
@@ -135,7 +148,10 @@ def main():
     allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
     step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce)
 
+    torch.set_num_threads(host_cores())
     ring = [b.to(dev) for b in synth_batches(8, args.batch, 1234 + rank)]
+    if rank == 0:
+        log('model built (%d params), warming up' % sum(p.numel() for p in model.parameters()))
     for i in range(max(args.warmup, 3)):  # >= 3: two eager steps + the capture replay
         step(ring[i % 8])
     torch.cuda.synchronize()
@@ -154,6 +170,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss, elbo = float(out['loss']), float(out['elbo'])
+    if rank == 0:
+        log('timed %d steps: %.2f ms/step' % (args.steps, dt / args.steps * 1e3))
 
     line = None
     if rank == 0:
@@ -177,6 +195,7 @@ def main():
                             'launches': n, 'avg_launch_us': ms_conv * 1e3 / n, 'flops_per_step': f,
                             'conv_ms_per_step': ms_conv}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('cpu baseline on %d host cores ...' % host_cores())
         line['cpu_baseline'] = cpu_baseline(CIFAR15, 32, 3)
     if rank == 0:
         print(json.dumps(line))

@@ -226,21 +226,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // dw[tap*stap + ci*sk + co*sn] += sum_ks slab[ks][tap][ci][co] ;  db[co] += sum_ks slab_b[ks][co]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slab_w, const float* slab_b, int ksplit,
-                                                            int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
+// 256 threads = 64 elements x 4 ksplit lanes: coalesced over elements, 4-way parallel over ks, fixed combine order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
+                                                            int ksplit, int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
                                                             int64_t sn, float* dw, float* db) {
+  __shared__ float red[4][64];
   const int per = ntaps * Cin * Cout;
-  int idx = blockIdx.x * 256 + threadIdx.x;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  float s = 0.f;
   if (idx < per) {
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += slab_w[(size_t)k * per + idx];
+    for (int k = q; k < ksplit; k += 4) s += slab_w[(size_t)k * per + idx];
+  } else if (db && idx < per + Cout) {
+    for (int k = q; k < ksplit; k += 4) s += slab_b[(size_t)k * Cout + (idx - per)];
+  }
+  red[q][e] = s;
+  __syncthreads();
+  if (q != 0) return;
+  s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  if (idx < per) {
     const int co = idx % Cout, r = idx / Cout, ci = r % Cin, tap = r / Cin;
     dw[tap * stap + ci * sk + co * sn] += s;
   } else if (db && idx < per + Cout) {
-    const int co = idx - per;
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += slab_b[(size_t)k * Cout + co];
-    db[co] += s;
+    db[idx - per] += s;
   }
 }
 
@@ -250,6 +258,7 @@ static void wgrad_plan(const lvae_conv_desc* d, int& ksplit, int& px_per_split, 
   ncot = (d->Cout + CT - 1) / CT;
   const int tiles = ntaps * ncit * ncot;
   int want = (512 + tiles - 1) / tiles;           // ~2 workgroups per CU in total
+  if (want > 64) want = 64;                       // bound the slab traffic of small (1x1) filters
   int maxsplit = (M + 255) / 256;                 // at least 8 stages per workgroup
   ksplit = want < 1 ? 1 : want;
   if (ksplit > maxsplit) ksplit = maxsplit;
@@ -300,7 +309,7 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   else hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
   LVAE_LAUNCH_CHECK("conv2d_wgrad");
   const int per = a.ntaps * a.Cin * d->Cout + (db ? d->Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, s, a.slab_w, a.slab_b, a.ksplit,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 63) / 64), dim3(256), 0, s, a.slab_w, a.slab_b, a.ksplit,
                      a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
   LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return 0;

@@ -6,7 +6,7 @@
 
 namespace lvae {
 
-constexpr int kMaxChunks = 512;
+constexpr int kMaxChunks = 256;
 
 struct RowMap {
   int cols;   // float4 (or scalar) columns per row handled by distinct threads
@@ -21,7 +21,7 @@ static inline RowMap row_map(int C, int vec) {
 }
 
 static inline int chunk_count(int64_t M, int rpp) {
-  int64_t want = (M + (int64_t)rpp * 8 - 1) / ((int64_t)rpp * 8);
+  int64_t want = (M + (int64_t)rpp * 16 - 1) / ((int64_t)rpp * 16);
   if (want < 1) want = 1;
   if (want > kMaxChunks) want = kMaxChunks;
   return (int)want;
@@ -99,25 +99,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  // Chan et al. pairwise combination, in double, fixed chunk order
+__device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+  if (nb <= 0.0) return;
+  if (n <= 0.0) {
+    n = nb; mean = mb; m2 = m2b;
+    return;
+  }
+  const double delta = mb - mean, nt = n + nb;
+  mean += delta * nb / nt;
+  m2 += m2b + delta * delta * n * nb / nt;
+  n = nt;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, o, 64);
+  hi = __shfl_xor(hi, o, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// one wave per channel: lane k combines chunks k, k+64, ... (Chan et al., double), then a fixed xor-shuffle tree
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
+                                                         const float* gamma, const float* beta, float eps, float momentum,
+                                                         float* running_mean, float* running_var, float* scale,
+                                                         float* shift, float* mean_out, float* rstd_out) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* p = ws + (size_t)k * 4 * C;
     const double nb = p[3 * C + c];
     if (nb <= 0.0) continue;
     const double s1 = p[C + c], s2 = p[2 * C + c];
-    const double mb = (double)p[c] + s1 / nb;
-    const double m2b = s2 - s1 * s1 / nb;
-    const double delta = mb - mean, nt = n + nb;
-    mean += delta * nb / nt;
-    m2 += m2b + delta * delta * n * nb / nt;
-    n = nt;
+    chan_combine(n, mean, m2, nb, (double)p[c] + s1 / nb, s2 - s1 * s1 / nb);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double nb = shfl_xor_d(n, o), mb = shfl_xor_d(mean, o), m2b = shfl_xor_d(m2, o);
+    // combine in a lane-order independent way: lower lane index is always the left operand
+    if ((lane & o) == 0) chan_combine(n, mean, m2, nb, mb, m2b);
+    else {
+      double n2 = nb, me2 = mb, mm2 = m2b;
+      chan_combine(n2, me2, mm2, n, mean, m2);
+      n = n2; mean = me2; m2 = mm2;
+    }
+  }
+  if (lane != 0) return;
   const double var = m2 / (double)M;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -223,15 +249,20 @@ __global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __
 }
 
 // coef layout (tail of ws): [2][C] = (mean g, mean g*xhat)
-__global__ void affine_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M, float* dgamma,
-                                           float* dbeta, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void affine_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
+                                                                 float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     a += ws[(size_t)k * 2 * C + c];
     b += ws[(size_t)k * 2 * C + C + c];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += shfl_xor_d(a, o);
+    b += shfl_xor_d(b, o);
+  }
+  if (lane != 0) return;
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   coef[c] = (float)(a / (double)M);
@@ -379,7 +410,7 @@ extern "C" int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const flo
   else
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(used), dim3(256), 0, s, x, M, C, rm.cols, rm.rpp, rpc, ws);
   LVAE_LAUNCH_CHECK("bn_partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, mean, rstd);
   LVAE_LAUNCH_CHECK("bn_finalize");
   return 0;
@@ -442,7 +473,7 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
       hipLaunchKernelGGL(affine_bwd_partial_kernel<1>, dim3(used), dim3(256), 0, s, dh, x, M, C, rm.cols, rm.rpp, rpc,
                          scale, shift, act, mean, rstd, ws);
     LVAE_LAUNCH_CHECK("affine_bwd_partial");
-    hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, used, C, M, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, used, C, M, dgamma, dbeta, coef);
     LVAE_LAUNCH_CHECK("affine_bwd_finalize");
   }
   if (v4) {
