@@ -1,0 +1,305 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and dgrad) with the input patch resident in LDS.
+//
+// The generic implicit-GEMM kernel (conv_igemm.hip) re-gathers the A tile from L2 for each of the 9 taps and
+// recomputes the fused BatchNorm-apply + ELU 9 times per element; measured on MI355X it is L2-load bound at
+// ~27 % of the fp32 MFMA peak. Here a workgroup stages the (TH+2) x (W+2) x Cin halo patch of its output tile
+// ONCE (coalesced 16-B loads, input transform applied once per element, zero padding materialised), then runs the
+// 9 taps x Cin reduction out of LDS: per tap only a 64 x Cin weight tile (16 KB, L2 resident) is streamed,
+// double buffered against the MFMAs. A-fragments are ds_read_b128 at (pixel + tap offset) rows, padded to 68 floats.
+//
+// Tile: BM output pixels = NI images x TH rows x TW (= W) columns, BN = 64 output channels, 4 waves as 2(M) x 2(N).
+#include <stdlib.h>
+
+#include "lvae_common.h"
+
+namespace lvae {
+
+int conv_desc_check(const lvae_conv_desc* d, const char* who);
+
+struct HaloArgs {
+  lvae_conv_desc d;
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, flip, Cin, debug;
+};
+
+template <int BM, int CIN_T, bool B_KCONTIG>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
+  constexpr int LDA = CIN_T + 4;   // A / k-contiguous B row stride (floats)
+  constexpr int LDN = 64;          // n-contiguous B row stride
+  constexpr int WMT = BM / 2, MI = WMT / 32;
+  constexpr int CIN4 = CIN_T / 4;
+  constexpr int KS = 32;           // reduction channels per stage (half a tap at Cin = 64): keeps LDS <= 80 KB -> 2 WGs/CU
+  constexpr int KS4 = KS / 4;
+  constexpr int LDB = KS + 4;      // k-contiguous B row stride
+  constexpr int SPT = CIN_T / KS;  // stages per tap
+  constexpr int BBUF = 64 * LDB;   // floats per B buffer (covers both layouts: 64 x 36 >= 32 x 64)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + (size_t)a.halo_px * LDA;
+
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.ntn;
+  const int tm = bid / a.ntn;
+  const int th_idx = tm % a.tiles_h, ig = tm / a.tiles_h;
+  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
+  const int Cin = a.Cin;
+
+  // ---- weight tile of one stage (tap, 32-channel half): global -> register ring (RING stages in flight) -> LDS.
+  // One stage is only 16-32 MFMAs per wave (0.4-0.9 us), shorter than an L2 round trip, so loads run RING stages ahead.
+  constexpr int RING = 3;
+  f32x4 breg[RING][2];
+  auto load_b = [&](int stage, f32x4 (&r)[2]) {
+    const int tap = stage / SPT, k0 = (stage - tap * SPT) * KS;
+    const float* wt = d.w + (int64_t)tap * d.w_stap;
+    if (B_KCONTIG) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = (t >> 3) + 32 * p, k = k0 + (t & 7) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (co0 + n < d.Cout && k < Cin) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)(co0 + n) * d.w_sn + k);
+        r[p] = v;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int k = k0 + (t >> 4) + 16 * p, n = (t & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < Cin && co0 + n < d.Cout) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d.w_sk + co0 + n);
+        r[p] = v;
+      }
+    }
+  };
+  auto store_b = [&](int buf, const f32x4 (&r)[2]) {
+    float* Bb = Bs + buf * BBUF;
+    if (B_KCONTIG) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(Bb + ((t >> 3) + 32 * p) * LDB + (t & 7) * 4) = r[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(Bb + ((t >> 4) + 16 * p) * LDN + (t & 15) * 4) = r[p];
+    }
+  };
+
+  constexpr int NST = 9 * SPT;
+#pragma unroll
+  for (int q = 0; q < RING; ++q) load_b(q, breg[q]);
+
+  // ---- halo patch: every (pixel, 4 channels) once, transform fused, zeros outside the image / batch
+  if (!(a.debug & 1)) {
+    const int per_img = a.halo_h * a.halo_w;
+    const int total = a.halo_px * CIN4;
+    for (int base = t; base < total; base += 256 * 8) {
+      f32x4 v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + 256 * u;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dst[u] = -1;
+        if (idx < total) {
+          const int px = idx / CIN4, c4 = (idx - px * CIN4) * 4;
+          const int img = px / per_img, r = px - img * per_img;
+          const int hy = r / a.halo_w, hx = r - hy * a.halo_w;
+          const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+          dst[u] = px * LDA + c4;
+          if (n < d.N && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && c4 < Cin) {
+            v[u] = *reinterpret_cast<const f32x4*>(d.x + ((size_t)(n * d.H + ih) * d.W + iw) * Cin + c4);
+            dst[u] |= 0x40000000;  // loaded from memory: apply the input transform
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (dst[u] >= 0 && (dst[u] & 0x40000000)) {
+          dst[u] &= 0x3fffffff;
+          if (d.in_scale) {
+            const int c4 = dst[u] % LDA;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
+            f32x4 x = v[u] * sc + sh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = act_fwd(x[j], d.in_act);
+            v[u] = x;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(As + dst[u]) = v[u];
+    }
+  }
+  store_b(0, breg[0]);
+
+  // ---- per-lane halo row of its A-fragment pixels
+  const int tile_px = a.NI * a.TH * a.TW;
+  int hbase[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int p = wm * WMT + mi * 32 + li;
+    if (p >= tile_px) p = 0;  // masked rows read a valid address; their results are never stored
+    const int img = p / (a.TH * a.TW), r = p - img * (a.TH * a.TW);
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    hbase[mi] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDA + 4 * lh;
+  }
+
+  f32x16 acc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+  __syncthreads();
+
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    if (a.debug & 4) break;
+    const int buf = st & 1;
+    if (st + RING < NST) load_b(st + RING, breg[st % RING]);  // slot st % RING was stored to LDS one stage ago
+    const int tap = st / SPT, k0 = (st - tap * SPT) * KS;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
+    const int tapoff = (dh * a.halo_w + dw) * LDA + k0;
+    const float* Bb = Bs + buf * BBUF;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += 8) {
+      f32x4 af[MI], bf;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(As + hbase[mi] + tapoff + kk);
+      if (B_KCONTIG) {
+        bf = *reinterpret_cast<const f32x4*>(Bb + (wn * 32 + li) * LDB + kk + 4 * lh);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = Bb[(kk + 4 * lh + j) * LDN + wn * 32 + li];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[j], acc[mi], 0, 0, 0);
+    }
+    if (st + 1 < NST) store_b(buf ^ 1, breg[(st + 1) % RING]);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS tile [BM][64+4] (the halo image is dead after the last barrier) -> each
+  // thread stores 16 contiguous bytes of an NHWC row: whole 256-B rows per 16 lanes instead of 4-byte scatters.
+  constexpr int LDO = 68;
+  float* Os = smem;
+  if (!(a.debug & 2)) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Os[(wm * WMT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
+    __syncthreads();
+    const int c4 = (t & 15) * 4, col = co0 + c4;
+    const int thw = a.TH * a.TW;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias && col < d.Cout) bias = *reinterpret_cast<const f32x4*>(d.bias + col);  // Cout % 4 == 0 on this path
+#pragma unroll
+    for (int q = 0; q < BM / 16; ++q) {
+      const int p = (t >> 4) + 16 * q;
+      if (p >= tile_px || col >= d.Cout) continue;
+      const int img = p / thw, rr = p - img * thw;
+      const int n = n0 + img;
+      if (n >= d.N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Os + p * LDO + c4) + bias;
+      if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
+      if (d.out_act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.out_act);
+      }
+      // tile pixels of one image are contiguous in memory: (oh0*W + rr) since TW == W
+      *reinterpret_cast<f32x4*>(d.y + ((size_t)(n * d.H + oh0) * d.W + rr) * d.Cout + col) = v;
+    }
+  }
+}
+
+constexpr int kHaloNotEligible = -1000;
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// tile geometry for a W-wide image: rows per tile and images per tile so that NI*TH*W <= BM
+static bool halo_plan(int N, int H, int W, int BM, int cin_t, HaloArgs& a) {
+  if (W > BM) return false;
+  int TH = 1;
+  for (int c = 1; c <= H; ++c)
+    if (H % c == 0 && c * W <= BM) TH = c;
+  int NI = BM / (TH * W);
+  if (NI < 1) NI = 1;
+  if (TH < H) NI = 1;  // partial images are not packed with others
+  if (NI > N) NI = N;
+  a.TH = TH;
+  a.TW = W;
+  a.NI = NI;
+  a.tiles_h = H / TH;
+  a.halo_h = TH + 2;
+  a.halo_w = W + 2;
+  a.halo_px = NI * a.halo_h * a.halo_w;
+  const size_t lds = ((size_t)a.halo_px * (cin_t + 4) + 2 * 64 * 36) * sizeof(float);
+  return lds <= 160 * 1024;
+}
+
+template <int BM, int CIN_T, bool B_KCONTIG>
+static int launch_halo(HaloArgs a, hipStream_t s) {
+  auto kern = conv3x3_halo_kernel<BM, CIN_T, B_KCONTIG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv3x3_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  size_t lds = ((size_t)a.halo_px * (CIN_T + 4) + 2 * 64 * 36) * sizeof(float);
+  if (lds < (size_t)BM * 68 * sizeof(float)) lds = (size_t)BM * 68 * sizeof(float);  // epilogue staging tile
+  const int img_groups = (a.d.N + a.NI - 1) / a.NI;
+  a.ntn = (a.d.Cout + 63) / 64;
+  hipLaunchKernelGGL(kern, dim3(img_groups * a.tiles_h * a.ntn), dim3(256), lds, s, a);
+  LVAE_LAUNCH_CHECK("conv3x3_halo");
+  return 0;
+}
+
+// returns kHaloNotEligible when the descriptor does not fit this kernel (the caller then uses the generic one)
+int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
+  const int Cin = d->C1;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return kHaloNotEligible;
+  if (Cin > 64 || Cin % 4 != 0 || !al16(d->x) || !al16(d->w) || d->w_stap % 4 != 0) return kHaloNotEligible;
+  if (d->in_scale && (!al16(d->in_scale) || !al16(d->in_shift))) return kHaloNotEligible;
+  const bool kcontig = d->w_sk == 1 && d->w_sn % 4 == 0;
+  const bool ncontig = d->w_sn == 1 && d->w_sk % 4 == 0 && d->Cout % 4 == 0;
+  if (!kcontig && !ncontig) return kHaloNotEligible;
+  if (d->Cout % 4 != 0 || !al16(d->y) || (d->bias && !al16(d->bias)) || (d->out_scale && !al16(d->out_scale))) return kHaloNotEligible;
+  const int cin_t = Cin <= 32 ? 32 : 64;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  HaloArgs a;
+  a.d = *d;
+  a.Cin = Cin;
+  a.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
+  static const int dbg = getenv("LVAE_HALO_DEBUG") ? atoi(getenv("LVAE_HALO_DEBUG")) : 0;  // phase-skip switch, profiling only
+  a.debug = dbg;
+  int BM = M >= 128 * 192 ? 128 : 64;
+  if (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) {
+    BM = 64;
+    if (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) return kHaloNotEligible;
+  }
+  // n-contiguous weights take precedence when both hold (Cin == 1 cannot reach here)
+  const bool kc = !ncontig;
+  if (BM == 128) {
+    if (cin_t == 64) return kc ? launch_halo<128, 64, true>(a, s) : launch_halo<128, 64, false>(a, s);
+    return kc ? launch_halo<128, 32, true>(a, s) : launch_halo<128, 32, false>(a, s);
+  }
+  if (cin_t == 64) return kc ? launch_halo<64, 64, true>(a, s) : launch_halo<64, 64, false>(a, s);
+  return kc ? launch_halo<64, 32, true>(a, s) : launch_halo<64, 32, false>(a, s);
+}
+
+}  // namespace lvae

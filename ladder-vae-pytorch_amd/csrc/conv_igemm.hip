@@ -13,6 +13,8 @@
 // MFMA accumulators. K is consumed in stages of KC = 32 channels of one tap; A and B stages are double
 // buffered in LDS with k-contiguous rows padded to 36 floats so that the ds_read_b128 fragment reads of 32
 // consecutive rows are bank-conflict free; global loads of stage s+1 are issued before the MFMAs of stage s.
+#include <stdlib.h>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -351,6 +353,8 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
   return 0;
 }
 
+int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s);
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace lvae
@@ -361,6 +365,11 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv2d_f32");
   if (rc) return rc;
   LVAE_REQUIRE(d->y != nullptr, LVAE_EINVAL, "lvae_conv2d_f32: null y");
+  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
+  if (!halo_off) {
+    const int hr = conv3x3_halo_try(d, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
   ConvArgs a;
   a.d = *d;
   a.M = d->N * d->OH * d->OW;

@@ -7,6 +7,8 @@
 // ds_read_b32 of 32 consecutive channels (conflict free). The pixel range is split over `ksplit` workgroups
 // per (tap, ci-tile, co-tile); each writes its 64x64 partial to a slab, and a second kernel sums the slabs in a
 // fixed order (bitwise reproducible, no float atomics) and accumulates into the gradient arena.
+#include <stdlib.h>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -252,6 +254,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, int ntaps, int Cin, int Cout, int64_t stap,
+                         int64_t sk, int64_t sn, float* dw, float* db, hipStream_t s) {
+  const int per = ntaps * Cin * Cout + (db ? Cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 63) / 64), dim3(256), 0, s, slab_w, slab_b, ksplit, ntaps, Cin, Cout,
+                     stap, sk, sn, dw, db);
+}
+
+size_t conv3x3_wgrad_halo_workspace(const lvae_conv_desc* d);
+int conv3x3_wgrad_halo_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
+
 static void wgrad_plan(const lvae_conv_desc* d, int& ksplit, int& px_per_split, int& ncit, int& ncot) {
   const int Cin = d->C1 + d->C2, M = d->N * d->OH * d->OW, ntaps = d->KH * d->KW;
   ncit = (Cin + CT - 1) / CT;
@@ -274,6 +286,8 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
+  const size_t halo = conv3x3_wgrad_halo_workspace(d);
+  if (halo) return halo;
   int ksplit, pps, ncit, ncot;
   wgrad_plan(d, ksplit, pps, ncit, ncot);
   const size_t per = (size_t)d->KH * d->KW * (d->C1 + d->C2) * d->Cout + d->Cout;
@@ -287,6 +301,11 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(dy && dw && workspace, LVAE_EINVAL, "lvae_conv2d_wgrad_f32: null dy/dw/workspace");
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
+  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  if (!halo_off && conv3x3_wgrad_halo_workspace(d)) {
+    const int hr = conv3x3_wgrad_halo_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
   WgradArgs a;
   a.d = *d;
   a.dy = dy;

@@ -172,24 +172,31 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* be
 // ---------------------------------------------------------------------------------------------------------
 // y = act(x*scale + shift) * row_scale[n, c]
 // ---------------------------------------------------------------------------------------------------------
+// Row-major mapping shared by the streaming kernels below: thread -> (row group rg, column col) once; rows advance by
+// a fixed stride, so the loop body has no integer division (only n = row / rows_per_n when a per-sample scale is used).
 template <int V>
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t total_v, int C,
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int M, int C, int cols, int rpp,
                                                           const float* scale, const float* shift, int act,
-                                                          const float* row_scale, int64_t rows_per_n,
+                                                          const float* row_scale, int rows_per_n,
                                                           float* __restrict__ y) {
-  const int cols = C / V;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cols;
-    const int c = (int)(i - row * cols) * V;
-    typename Vec<V>::T v = Vec<V>::load(x + i * V);
+  const int t = threadIdx.x, col = t % cols, rg = t / cols;
+  if (rg >= rpp) return;
+  const int c = col * V;
+  float sc[V], sh[V];
+  for (int j = 0; j < V; ++j) {
+    sc[j] = scale ? scale[c + j] : 1.f;
+    sh[j] = scale ? shift[c + j] : 0.f;
+  }
+  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
+    const size_t off = (size_t)row * C + c;
+    typename Vec<V>::T v = Vec<V>::load(x + off);
+    const float* rs = row_scale ? row_scale + (size_t)(row / rows_per_n) * C + c : nullptr;
     for (int j = 0; j < V; ++j) {
-      float u = at<V>(v, j);
-      if (scale) u = u * scale[c + j] + shift[c + j];
-      u = act_fwd(u, act);
-      if (row_scale) u *= row_scale[(row / rows_per_n) * C + c + j];
+      float u = act_fwd(at<V>(v, j) * sc[j] + sh[j], act);
+      if (rs) u *= rs[j];
       at<V>(v, j) = u;
     }
-    Vec<V>::store(y + i * V, v);
+    Vec<V>::store(y + off, v);
   }
 }
 
@@ -271,30 +278,39 @@ __global__ __launch_bounds__(64) void affine_bwd_finalize_kernel(const float* __
 
 template <int V>
 __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ x,
-                                                                int64_t total_v, int C, const float* scale,
+                                                                int M, int C, int cols, int rpp, const float* scale,
                                                                 const float* shift, int act, const float* mean,
                                                                 const float* rstd, const float* coef,
-                                                                const float* drop, int64_t rows_per_n,
+                                                                const float* drop, int rows_per_n,
                                                                 const float* __restrict__ add, float* __restrict__ dx) {
-  const int cols = C / V;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cols;
-    const int c = (int)(i - row * cols) * V;
-    typename Vec<V>::T xv = Vec<V>::load(x + i * V);
-    typename Vec<V>::T gv = Vec<V>::load(dh + i * V);
+  const int t = threadIdx.x, col = t % cols, rg = t / cols;
+  if (rg >= rpp) return;
+  const int c = col * V;
+  float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
+  for (int j = 0; j < V; ++j) {
+    sc[j] = scale ? scale[c + j] : 1.f;
+    sh[j] = scale ? shift[c + j] : 0.f;
+    mu[j] = coef ? mean[c + j] : 0.f;
+    rs[j] = coef ? rstd[c + j] : 0.f;
+    c1[j] = coef ? coef[c + j] : 0.f;
+    c2[j] = coef ? coef[C + c + j] : 0.f;
+  }
+  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
+    const size_t off = (size_t)row * C + c;
+    typename Vec<V>::T xv = Vec<V>::load(x + off);
+    typename Vec<V>::T gv = Vec<V>::load(dh + off);
     typename Vec<V>::T av;
-    if (add) av = Vec<V>::load(add + i * V);
+    if (add) av = Vec<V>::load(add + off);
+    const float* dr = drop ? drop + (size_t)(row / rows_per_n) * C + c : nullptr;
     for (int j = 0; j < V; ++j) {
       const float xx = at<V>(xv, j);
-      const float sc = scale ? scale[c + j] : 1.f, sh = scale ? shift[c + j] : 0.f;
-      float g = at<V>(gv, j) * act_grad(xx * sc + sh, act);
-      if (coef) g = g - coef[c + j] - (xx - mean[c + j]) * rstd[c + j] * coef[C + c + j];
-      g *= sc;
-      if (drop) g *= drop[(row / rows_per_n) * C + c + j];
+      float g = at<V>(gv, j) * act_grad(xx * sc[j] + sh[j], act);
+      g = (g - c1[j] - (xx - mu[j]) * rs[j] * c2[j]) * sc[j];
+      if (dr) g *= dr[j];
       if (add) g += at<V>(av, j);
       at<V>(gv, j) = g;
     }
-    Vec<V>::store(dx + i * V, gv);
+    Vec<V>::store(dx + off, gv);
   }
 }
 
@@ -303,42 +319,45 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------------
 template <int V>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ ab, const float* __restrict__ res,
-                                                        int64_t total_v, int C, int act, float* __restrict__ out) {
-  const int cols = C / V;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cols;
-    const int c = (int)(i - row * cols) * V;
-    typename Vec<V>::T a = Vec<V>::load(ab + row * 2 * C + c);
-    typename Vec<V>::T b = Vec<V>::load(ab + row * 2 * C + C + c);
+                                                        int M, int C, int cols, int rpp, int act, float* __restrict__ out) {
+  const int t = threadIdx.x, col = t % cols, rg = t / cols;
+  if (rg >= rpp) return;
+  const int c = col * V;
+  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
+    const float* pa = ab + (size_t)row * 2 * C + c;
+    typename Vec<V>::T a = Vec<V>::load(pa);
+    typename Vec<V>::T b = Vec<V>::load(pa + C);
     typename Vec<V>::T r;
-    if (res) r = Vec<V>::load(res + i * V);
+    if (res) r = Vec<V>::load(res + (size_t)row * C + c);
     for (int j = 0; j < V; ++j) {
       float o = act_fwd(at<V>(a, j), act) * sigmoidf_(at<V>(b, j));
       if (res) o += at<V>(r, j);
       at<V>(a, j) = o;
     }
-    Vec<V>::store(out + i * V, a);
+    Vec<V>::store(out + (size_t)row * C + c, a);
   }
 }
 
 template <int V>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ab,
-                                                        int64_t total_v, int C, int act, float* __restrict__ dab) {
-  const int cols = C / V;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_v; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cols;
-    const int c = (int)(i - row * cols) * V;
-    typename Vec<V>::T a = Vec<V>::load(ab + row * 2 * C + c);
-    typename Vec<V>::T b = Vec<V>::load(ab + row * 2 * C + C + c);
-    typename Vec<V>::T g = Vec<V>::load(dout + i * V);
+                                                        int M, int C, int cols, int rpp, int act, float* __restrict__ dab) {
+  const int t = threadIdx.x, col = t % cols, rg = t / cols;
+  if (rg >= rpp) return;
+  const int c = col * V;
+  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
+    const float* pa = ab + (size_t)row * 2 * C + c;
+    typename Vec<V>::T a = Vec<V>::load(pa);
+    typename Vec<V>::T b = Vec<V>::load(pa + C);
+    typename Vec<V>::T g = Vec<V>::load(dout + (size_t)row * C + c);
     for (int j = 0; j < V; ++j) {
       const float s = sigmoidf_(at<V>(b, j));
       const float aa = at<V>(a, j), gg = at<V>(g, j);
       at<V>(a, j) = gg * s * act_grad(aa, act);
       at<V>(b, j) = gg * act_fwd(aa, act) * s * (1.f - s);
     }
-    Vec<V>::store(dab + row * 2 * C + c, a);
-    Vec<V>::store(dab + row * 2 * C + C + c, b);
+    float* pd = dab + (size_t)row * 2 * C + c;
+    Vec<V>::store(pd, a);
+    Vec<V>::store(pd + C, b);
   }
 }
 
@@ -431,15 +450,17 @@ extern "C" int lvae_affine_act_f32(const float* x, int64_t M, int32_t C, const f
   LVAE_REQUIRE((scale == nullptr) == (shift == nullptr), LVAE_EINVAL, "lvae_affine_act_f32: scale/shift pair");
   LVAE_REQUIRE(!row_scale || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_f32: rows_per_n");
   hipStream_t s = (hipStream_t)stream;
-  if (vec_ok(C, x, y)) {
-    const int64_t tv = M * (C / 4);
-    hipLaunchKernelGGL(affine_act_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, x, tv, C, scale, shift, act,
-                       row_scale, rows_per_n, y);
-  } else {
-    const int64_t tv = M * C;
-    hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, x, tv, C, scale, shift, act,
-                       row_scale, rows_per_n, y);
-  }
+  LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_f32: too many rows");
+  const bool v4 = vec_ok(C, x, y);
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_affine_act_f32: C=%d unsupported", C);
+  const RowMap rm = row_map(C, v4 ? 4 : 1);
+  const int grid = grid_for(M, rm.rpp * 4);
+  if (v4)
+    hipLaunchKernelGGL(affine_act_kernel<4>, dim3(grid), dim3(256), 0, s, x, (int)M, C, rm.cols, rm.rpp, scale, shift, act,
+                       row_scale, (int)rows_per_n, y);
+  else
+    hipLaunchKernelGGL(affine_act_kernel<1>, dim3(grid), dim3(256), 0, s, x, (int)M, C, rm.cols, rm.rpp, scale, shift, act,
+                       row_scale, (int)rows_per_n, y);
   LVAE_LAUNCH_CHECK("affine_act");
   return 0;
 }
@@ -476,14 +497,17 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
     hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, used, C, M, dgamma, dbeta, coef);
     LVAE_LAUNCH_CHECK("affine_bwd_finalize");
   }
-  if (v4) {
-    const int64_t tv = M * (C / 4);
-    hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dh, x, tv, C, scale, shift,
-                       act, mean, rstd, coef, drop, rows_per_n, add, dx);
-  } else {
-    const int64_t tv = M * C;
-    hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dh, x, tv, C, scale, shift,
-                       act, mean, rstd, coef, drop, rows_per_n, add, dx);
+  LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_bwd_f32: too many rows");
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_affine_act_bwd_f32: C=%d unsupported", C);
+  {
+    const RowMap rm2 = row_map(C, v4 ? 4 : 1);
+    const int grid = grid_for(M, rm2.rpp * 4);
+    if (v4)
+      hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale,
+                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+    else
+      hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale,
+                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
   }
   LVAE_LAUNCH_CHECK("affine_bwd_apply");
   return 0;
@@ -493,13 +517,13 @@ extern "C" int lvae_gate_fwd_f32(const float* ab, const float* res, int64_t M, i
                                  void* stream) {
   LVAE_REQUIRE(ab && out && M > 0 && C > 0, LVAE_EINVAL, "lvae_gate_fwd_f32: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (vec_ok(C, ab, res, out)) {
-    const int64_t tv = M * (C / 4);
-    hipLaunchKernelGGL(gate_fwd_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, ab, res, tv, C, act, out);
-  } else {
-    const int64_t tv = M * C;
-    hipLaunchKernelGGL(gate_fwd_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, ab, res, tv, C, act, out);
-  }
+  LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_gate_fwd_f32: too many rows");
+  const bool v4 = vec_ok(C, ab, res, out);
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_gate_fwd_f32: C=%d unsupported", C);
+  const RowMap rm = row_map(C, v4 ? 4 : 1);
+  const int grid = grid_for(M, rm.rpp * 4);
+  if (v4) hipLaunchKernelGGL(gate_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, ab, res, (int)M, C, rm.cols, rm.rpp, act, out);
+  else hipLaunchKernelGGL(gate_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, ab, res, (int)M, C, rm.cols, rm.rpp, act, out);
   LVAE_LAUNCH_CHECK("gate_fwd");
   return 0;
 }
@@ -508,13 +532,13 @@ extern "C" int lvae_gate_bwd_f32(const float* dout, const float* ab, int64_t M, 
                                  void* stream) {
   LVAE_REQUIRE(dout && ab && dab && M > 0 && C > 0, LVAE_EINVAL, "lvae_gate_bwd_f32: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (vec_ok(C, ab, dout, dab)) {
-    const int64_t tv = M * (C / 4);
-    hipLaunchKernelGGL(gate_bwd_kernel<4>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dout, ab, tv, C, act, dab);
-  } else {
-    const int64_t tv = M * C;
-    hipLaunchKernelGGL(gate_bwd_kernel<1>, dim3(grid_for(tv, 256)), dim3(256), 0, s, dout, ab, tv, C, act, dab);
-  }
+  LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_gate_bwd_f32: too many rows");
+  const bool v4 = vec_ok(C, ab, dout, dab);
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_gate_bwd_f32: C=%d unsupported", C);
+  const RowMap rm = row_map(C, v4 ? 4 : 1);
+  const int grid = grid_for(M, rm.rpp * 4);
+  if (v4) hipLaunchKernelGGL(gate_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, dout, ab, (int)M, C, rm.cols, rm.rpp, act, dab);
+  else hipLaunchKernelGGL(gate_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, dout, ab, (int)M, C, rm.cols, rm.rpp, act, dab);
   LVAE_LAUNCH_CHECK("gate_bwd");
   return 0;
 }

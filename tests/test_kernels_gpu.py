@@ -48,6 +48,12 @@ CONV_CASES = [
     (70, 64, 64, 16, 16, 3, 1, 1),   # > 128 tiles: BM = 128 path
     (40, 64, 128, 16, 16, 1, 1, 0),  # BM = 128, BN = 128
     (2, 8, 8, 2, 2, 3, 1, 1),
+    (3, 64, 64, 8, 8, 3, 1, 1),      # halo kernel: 2 images per tile, ragged last tile
+    (37, 64, 64, 4, 4, 3, 1, 1),     # halo kernel: 4 or 8 images per tile
+    (50, 32, 64, 2, 2, 3, 1, 1),
+    (9, 64, 64, 32, 32, 3, 1, 1),    # 4-row tiles of a 32-wide image
+    (2, 64, 64, 12, 12, 3, 1, 1),    # width that does not divide the tile
+    (130, 64, 64, 16, 16, 3, 1, 1),
 ]
 
 
