@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--sync-wgrad', action='store_true', help='keep weight-gradient kernels on the main stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -146,7 +147,7 @@ def main():
     ldist.broadcast_flat(arena.params)
     opt = Adamax(model, lr=3e-4)
     allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
-    step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce)
+    step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce, async_wgrad=not args.sync_wgrad)
 
     torch.set_num_threads(host_cores())
     ring = [b.to(dev) for b in synth_batches(8, args.batch, 1234 + rank)]

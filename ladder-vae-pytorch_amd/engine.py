@@ -35,8 +35,9 @@ def forward_pass(model, x, beta=1.0, compute_l2=True):
 class TrainStep:
     """step(x) -> dict of scalars (device tensors, valid until the next step)."""
 
-    def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2):
+    def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2, async_wgrad=True):
         self.model, self.opt, self.beta = model, optimizer, beta
+        self.side = torch.cuda.Stream(device=next(model.parameters()).device) if async_wgrad else None
         self.use_graph, self.allreduce = use_graph, allreduce
         self.eager_left = eager_warmup if use_graph else -1
         self.graph_a = self.graph_b = None
@@ -50,7 +51,14 @@ class TrainStep:
     def _fwd_bwd(self, x):
         self.opt.zero_grad()
         out = forward_pass(self.model, x, self.beta)
-        out['loss'].backward()
+        ops.set_wgrad_stream(self.side)
+        try:
+            if self.side is not None:
+                self.side.wait_stream(torch.cuda.current_stream())  # zero_grad happens-before every wgrad accumulate
+            out['loss'].backward()
+            ops.join_wgrad_stream()
+        finally:
+            ops.set_wgrad_stream(None)
         return {k: out[k].detach() for k in ('loss', 'elbo', 'recons', 'kl', 'l2', 'kl_avg_layerwise')}
 
     def _eager(self, x):
@@ -81,15 +89,16 @@ class TrainStep:
         if not self.use_graph or self.eager_left > 0:
             self.eager_left -= 1
             return self._eager(x)
-        if self.graph_a is None:
-            self._capture(x)
+        just_captured = self.graph_a is None
+        if just_captured:
+            self._capture(x)  # the Python forward ran once while capturing: it already counted this step's BN forwards
         else:
             self.static_x.copy_(x, non_blocking=True)
         self.graph_a.replay()
         if self.graph_b is not None:
             self.allreduce.run()
             self.graph_b.replay()
-        if self.model.training:
+        if self.model.training and not just_captured:
             for bn in self._bns:
                 bn._pending += 1
         return self.static_out

@@ -16,7 +16,7 @@ _ws_cache = {}
 
 def workspace(nbytes, device):
     """A per-device scratch buffer, grown on demand. Kernels run in stream order, so one buffer is enough."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream if False else 0)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)  # one scratch buffer per launch stream
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes or buf.device != device:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

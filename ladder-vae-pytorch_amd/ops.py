@@ -35,6 +35,36 @@ def _c(t):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Weight-gradient kernels feed nothing but the optimiser, so they do not have to sit on the critical path of the
+# backward chain: with a side stream set (engine.TrainStep does it) every wgrad launch goes there, ordered after the
+# producer of dy by a stream dependency, and the main stream joins once at the end of backward. Inside a captured
+# hipGraph these become parallel branches. The scratch slabs are per stream (kernels.workspace).
+_side = {'stream': None}
+
+
+def set_wgrad_stream(stream):
+    _side['stream'] = stream
+
+
+def join_wgrad_stream():
+    st = _side['stream']
+    if st is not None:
+        torch.cuda.current_stream().wait_stream(st)
+
+
+def wgrad(x, dy, w, g, dw, db, **kw):
+    st = _side['stream']
+    if st is None:
+        return K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)
+    for t in (x, dy, kw.get('x2'), kw.get('in_scale'), kw.get('in_shift')):
+        if t is not None:
+            t.record_stream(st)  # the caching allocator must not recycle these blocks before the side kernel ran
+
+
+# ----------------------------------------------------------------------------------------------------------------
 class ConvFn(Function):
     """y = out_act(conv(cat(x, x2)) + bias); call sites: stem, pre_conv (strided / transposed), merge 1x1,
     stochastic convs, likelihood head. `mod` is the parameter holder (lib.nn.Conv2dParams)."""
@@ -57,7 +87,7 @@ class ConvFn(Function):
             dy = K.act_bwd_from_out(dy, y, ctx.out_act)
         w = mod.weight
         if w.requires_grad:
-            K.conv2d_wgrad(x, dy, w, g, grad_buf(w), grad_buf(mod.bias) if mod.bias is not None else None, x2=x2)
+            wgrad(x, dy, w, g, grad_buf(w), grad_buf(mod.bias) if mod.bias is not None else None, x2=x2)
         dx = dx2 = None
         hw = (x.shape[1], x.shape[2])
         if x2 is None:
@@ -131,14 +161,13 @@ class ResBlockFn(Function):
         if blk.gate is not None:
             gw = blk.gate.weight
             dab = K.gate_bwd(dout, ab, act)
-            K.conv2d_wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
+            wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
             dy2 = K.conv2d_dgrad(dab, gw, blk.gate.geom(), hw, out_scale=m2)
         else:
             dy2 = K.scale_rows_add(dout, m2, None) if m2 is not None else dout
         # second half
         w2 = blk.conv2.weight
-        K.conv2d_wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2,
-                       in_act=act)
+        wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2, in_act=act)
         dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
         bn2 = blk.bn2
         train2 = bn2 is not None and ctx.training
@@ -146,8 +175,7 @@ class ResBlockFn(Function):
                                grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
         # first half
         w1 = blk.conv1.weight
-        K.conv2d_wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1,
-                       in_act=act)
+        wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
         dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
         bn1 = blk.bn1
         train1 = bn1 is not None and ctx.training
