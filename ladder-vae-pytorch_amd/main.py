@@ -1,0 +1,72 @@
+"""`python -m lvae_amd.main <flags>` — training entry point with the reference's flag surface (main.py:1-13 there is
+`Trainer(LVAEExperiment()).run()` on boilr; here a minimal loop on the HIP engine, one process per GPU).
+
+Launch N ranks with:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m lvae_amd.main ...
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import dist as ldist
+from .engine import TrainStep
+from .experiment.experiment_manager import LVAEExperiment
+
+
+def synthetic_batch(exp, batch, gen):
+    shape = (batch, exp.color_ch) + tuple(exp.img_size)
+    u = torch.rand(shape, generator=gen)
+    return (u > 0.5).float() if exp.args.likelihood == 'bernoulli' else torch.floor(256 * u) / 255
+
+
+def main(argv=None):
+    rank, world, local = ldist.init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    exp = LVAEExperiment(argv=argv)
+    args = exp.args
+    if not (args.synthetic or args.data_npz):
+        raise SystemExit("datasets cannot be downloaded here: pass --synthetic or --data-npz FILE")
+    model, opt = exp.model, exp.optimizer
+    model.noise.seed ^= rank * 0x9E3779B9
+    model.train()
+    arena = model.pack()
+    ldist.broadcast_flat(arena.params)
+    allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
+    step_fn = TrainStep(model, opt, beta=1.0, use_graph=not args.no_graph and args.beta_anneal == 0, allreduce=allreduce)
+    if rank == 0:
+        print(exp.run_description)
+        print('parameters: %d   world size: %d   per-rank batch: %d' % (sum(p.numel() for p in model.parameters()), world,
+                                                                       args.batch_size // world))
+    if args.batch_size % world:
+        raise SystemExit('--batch-size must be divisible by the world size')
+    per_rank = args.batch_size // world
+    data = None
+    if args.data_npz:
+        data = torch.from_numpy(np.load(args.data_npz)['data']).float()
+    gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
+    steps = args.steps or args.max_steps
+    t0, seen = time.time(), 0
+    for step in range(1, steps + 1):
+        if data is not None:
+            idx = torch.randint(0, data.shape[0], (args.batch_size,), generator=torch.Generator().manual_seed(args.seed + step))
+            lo, hi = ldist.shard_batch(args.batch_size, rank, world)
+            x = data[idx[lo:hi]]
+        else:
+            x = synthetic_batch(exp, per_rank, gen)
+        if args.beta_anneal != 0:
+            step_fn.beta = exp.beta()
+        out = step_fn(x.to(exp.device, non_blocking=True))
+        seen += args.batch_size
+        if rank == 0 and (step % args.log_every == 0 or step == steps):
+            m = exp.get_metrics_dict(out)
+            dt = time.time() - t0
+            print(exp.train_log_str(m, step) + '   [{:.0f} img/s]'.format(seen / dt))
+            t0, seen = time.time(), 0
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
