@@ -19,6 +19,7 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who);
 struct HaloArgs {
   lvae_conv_desc d;
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, flip, Cin, debug;
+  uint32_t m_thw, m_tw, m_per_img, m_halo_w;  // fastdiv magics
 };
 
 template <int BM, int CIN_T, bool B_KCONTIG>
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
         dst[u] = -1;
         if (idx < total) {
           const int px = idx / CIN4, c4 = (idx - px * CIN4) * 4;
-          const int img = px / per_img, r = px - img * per_img;
-          const int hy = r / a.halo_w, hx = r - hy * a.halo_w;
+          const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+          const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
           const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
           dst[u] = px * LDA + c4;
           if (n < d.N && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && c4 < Cin) {
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   for (int mi = 0; mi < MI; ++mi) {
     int p = wm * WMT + mi * 32 + li;
     if (p >= tile_px) p = 0;  // masked rows read a valid address; their results are never stored
-    const int img = p / (a.TH * a.TW), r = p - img * (a.TH * a.TW);
-    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
+    const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
     hbase[mi] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDA + 4 * lh;
   }
 
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     for (int q = 0; q < BM / 16; ++q) {
       const int p = (t >> 4) + 16 * q;
       if (p >= tile_px || col >= d.Cout) continue;
-      const int img = p / thw, rr = p - img * thw;
+      const int img = fastdiv(p, a.m_thw), rr = p - img * thw;
       const int n = n0 + img;
       if (n >= d.N) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(Os + p * LDO + c4) + bias;
@@ -243,6 +244,10 @@ static bool halo_plan(int N, int H, int W, int BM, int cin_t, HaloArgs& a) {
   a.halo_h = TH + 2;
   a.halo_w = W + 2;
   a.halo_px = NI * a.halo_h * a.halo_w;
+  a.m_thw = fastdiv_magic(TH * W);
+  a.m_tw = fastdiv_magic(W);
+  a.m_per_img = fastdiv_magic(a.halo_h * a.halo_w);
+  a.m_halo_w = fastdiv_magic(a.halo_w);
   const size_t lds = ((size_t)a.halo_px * (cin_t + 4) + 2 * 64 * 36) * sizeof(float);
   return lds <= 160 * 1024;
 }

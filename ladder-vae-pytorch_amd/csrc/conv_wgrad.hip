@@ -228,41 +228,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // dw[tap*stap + ci*sk + co*sn] += sum_ks slab[ks][tap][ci][co] ;  db[co] += sum_ks slab_b[ks][co]
-// 256 threads = 64 elements x 4 ksplit lanes: coalesced over elements, 4-way parallel over ks, fixed combine order.
+// The slab rows [taps*Cin*Cout | Cout] are contiguous and a multiple of 4 floats on the vector path: 256 threads =
+// 16 float4 elements x 16 split lanes (1 KB per wave load), LDS tree in a fixed order -> deterministic.
+template <int V>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
                                                             int ksplit, int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
                                                             int64_t sn, float* dw, float* db) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][16 * 4];
   const int per = ntaps * Cin * Cout;
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + e;
-  float s = 0.f;
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int idx = (blockIdx.x * 16 + e) * V;  // first float of this thread's element group
+  float s[V];
+  for (int j = 0; j < V; ++j) s[j] = 0.f;
+  const float* src = nullptr;
+  int64_t stride = 0;
   if (idx < per) {
-    for (int k = q; k < ksplit; k += 4) s += slab_w[(size_t)k * per + idx];
+    src = slab_w + idx;
+    stride = per;
   } else if (db && idx < per + Cout) {
-    for (int k = q; k < ksplit; k += 4) s += slab_b[(size_t)k * Cout + (idx - per)];
+    src = slab_b + (idx - per);
+    stride = Cout;
   }
-  red[q][e] = s;
+  if (src) {
+    for (int k = q; k < ksplit; k += 16) {
+      if (V == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+        for (int j = 0; j < 4; ++j) s[j] += v[j];
+      } else {
+        s[0] += src[(size_t)k * stride];
+      }
+    }
+  }
+  for (int j = 0; j < V; ++j) red[q][e * 4 + j] = s[j];
   __syncthreads();
-  if (q != 0) return;
-  s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-  if (idx < per) {
-    const int co = idx % Cout, r = idx / Cout, ci = r % Cin, tap = r / Cin;
-    dw[tap * stap + ci * sk + co * sn] += s;
-  } else if (db && idx < per + Cout) {
-    db[idx - per] += s;
+  if (q != 0 || !src) return;
+  for (int j = 0; j < V; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][e * 4 + j];
+    const int i = idx + j;
+    if (i < per) {
+      const int co = i % Cout, r2 = i / Cout, ci = r2 % Cin, tap = r2 / Cin;
+      dw[tap * stap + ci * sk + co * sn] += t;
+    } else if (i < per + Cout) {
+      db[i - per] += t;
+    }
   }
 }
 
 void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, int ntaps, int Cin, int Cout, int64_t stap,
                          int64_t sk, int64_t sn, float* dw, float* db, hipStream_t s) {
-  const int per = ntaps * Cin * Cout + (db ? Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 63) / 64), dim3(256), 0, s, slab_w, slab_b, ksplit, ntaps, Cin, Cout,
-                     stap, sk, sn, dw, db);
+  const int per = ntaps * Cin * Cout, tot = per + (db ? Cout : 0);
+  const bool v4 = (per % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(slab_w) & 15) == 0) &&
+                  (!slab_b || (reinterpret_cast<uintptr_t>(slab_b) & 15) == 0);
+  if (v4)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((tot / 4 + 15) / 16), dim3(256), 0, s, slab_w, slab_b, ksplit, ntaps, Cin,
+                       Cout, stap, sk, sn, dw, db);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((tot + 15) / 16), dim3(256), 0, s, slab_w, slab_b, ksplit, ntaps, Cin,
+                       Cout, stap, sk, sn, dw, db);
 }
 
-size_t conv3x3_wgrad_halo_workspace(const lvae_conv_desc* d);
-int conv3x3_wgrad_halo_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
+size_t conv_wgrad_tile_workspace(const lvae_conv_desc* d);
+int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 
 static void wgrad_plan(const lvae_conv_desc* d, int& ksplit, int& px_per_split, int& ncit, int& ncot) {
   const int Cin = d->C1 + d->C2, M = d->N * d->OH * d->OW, ntaps = d->KH * d->KW;
@@ -286,7 +314,7 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
-  const size_t halo = conv3x3_wgrad_halo_workspace(d);
+  const size_t halo = conv_wgrad_tile_workspace(d);
   if (halo) return halo;
   int ksplit, pps, ncit, ncot;
   wgrad_plan(d, ksplit, pps, ncit, ncot);
@@ -302,8 +330,8 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
-  if (!halo_off && conv3x3_wgrad_halo_workspace(d)) {
-    const int hr = conv3x3_wgrad_halo_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+  if (!halo_off && conv_wgrad_tile_workspace(d)) {
+    const int hr = conv_wgrad_tile_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
   }
   WgradArgs a;
@@ -327,9 +355,7 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   else if (yv) hipLaunchKernelGGL((conv_wgrad_kernel<false, true>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
   LVAE_LAUNCH_CHECK("conv2d_wgrad");
-  const int per = a.ntaps * a.Cin * d->Cout + (db ? d->Cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 63) / 64), dim3(256), 0, s, a.slab_w, a.slab_b, a.ksplit,
-                     a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
+  wgrad_reduce_launch(a.slab_w, a.slab_b, a.ksplit, a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
   LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return 0;
 }

@@ -85,6 +85,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// n / d for a run-time constant d via a host-computed magic number: exact for n, d < 65536
+// (M = ceil(2^32 / d): M*d - 2^32 < d, so the error term n*(M*d - 2^32) / 2^32 stays below 1).
+inline uint32_t fastdiv_magic(int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
+__device__ __forceinline__ int fastdiv(int n, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)n, magic) : n; }
+
 inline int grid_for(int64_t work_items, int per_block, int cap = 256 * 8) {
   int64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;

@@ -6,7 +6,7 @@
 
 namespace lvae {
 
-constexpr int kMaxChunks = 256;
+constexpr int kMaxChunks = 1024;  // ~4 workgroups per CU on the big layers; the finalize kernels are wave-parallel over chunks
 
 struct RowMap {
   int cols;   // float4 (or scalar) columns per row handled by distinct threads
@@ -21,7 +21,7 @@ static inline RowMap row_map(int C, int vec) {
 }
 
 static inline int chunk_count(int64_t M, int rpp) {
-  int64_t want = (M + (int64_t)rpp * 16 - 1) / ((int64_t)rpp * 16);
+  int64_t want = (M + (int64_t)rpp * 4 - 1) / ((int64_t)rpp * 4);
   if (want < 1) want = 1;
   if (want > kMaxChunks) want = kMaxChunks;
   return (int)want;

@@ -140,9 +140,18 @@ class LadderVAE(nn.Module):
     def bn_modules(self):
         return [m for m in self.modules() if isinstance(m, BatchNorm2dParams)]
 
-    def _begin(self, ref_tensor):
+    def _mask_plan(self, N):
+        """(number of Dropout2d draws of one training forward, N, C, p) when they all share one shape, else None."""
+        if not self.training or not self.dropout:
+            return None
+        if getattr(self, '_n_drop', None) is None:
+            from ..lib.nn import ResidualBlock
+            self._n_drop = sum(sum(m._drops) for m in self.modules() if isinstance(m, ResidualBlock))
+        return (self._n_drop, N, self.n_filters, float(self.dropout))
+
+    def _begin(self, ref_tensor, batch=None):
         self.pack(ref_tensor.device if ref_tensor is not None else None)
-        self.noise.begin(next(self.parameters()).device)
+        self.noise.begin(next(self.parameters()).device, self._mask_plan(batch) if batch else None)
 
     # ------------------------------------------------------------------------------------------------------------
     # reference API
@@ -150,7 +159,7 @@ class LadderVAE(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise K._C.LvaeHipError("LadderVAE (HIP engine) needs a GPU tensor; got %s" % x.device)
-        self._begin(x)
+        self._begin(x, batch=x.shape[0])
         img_size = x.size()[2:]
         x = x.contiguous().float()
         # NCHW image -> centred zero pad -> NHWC, one kernel (models/lvae.py:176, 317-325)

@@ -54,6 +54,8 @@ CONV_CASES = [
     (9, 64, 64, 32, 32, 3, 1, 1),    # 4-row tiles of a 32-wide image
     (2, 64, 64, 12, 12, 3, 1, 1),    # width that does not divide the tile
     (130, 64, 64, 16, 16, 3, 1, 1),
+    (40, 128, 64, 16, 16, 1, 1, 0),  # 1x1 tile wgrad with two ci blocks
+    (5, 64, 128, 4, 4, 1, 1, 0),
 ]
 
 
