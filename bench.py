@@ -57,7 +57,7 @@ def conv_roofline(model, x):
     orig = K.call
 
     def timed_call(name, *args):
-        if name != 'lvae_conv2d_f32':
+        if name not in ('lvae_conv2d_f32', 'lvae_conv1x1_gate_f32'):
             return orig(name, *args)
         d = args[0]._obj
         flops = 2.0 * d.N * d.OH * d.OW * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
@@ -192,7 +192,7 @@ def main():
         f, ms_conv, n = conv_roofline(model, ring[0])
         ach = f / (ms_conv * 1e-3) / 1e12
         line['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-                            'frac': ach / PEAK_MFMA_F32, 'traffic': None, 'kernel': 'conv_igemm_kernel (fwd+dgrad)',
+                            'frac': ach / PEAK_MFMA_F32, 'traffic': None, 'kernel': 'fp32-MFMA conv kernels: conv3x3_halo, conv1x1, conv_igemm (all forward + dgrad launches)',
                             'launches': n, 'avg_launch_us': ms_conv * 1e3 / n, 'flops_per_step': f,
                             'conv_ms_per_step': ms_conv}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

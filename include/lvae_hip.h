@@ -74,6 +74,13 @@ typedef struct lvae_conv_desc {
 
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
 
+/* GateLayer2d forward fused with its 1x1 convolution and the residual add — lib/nn.py:118-126 and lib/nn.py:99.
+ * `d` describes the 1x1 conv C -> 2C (d->y receives the pre-activations ab [N,H,W,2C] when non-NULL: the backward
+ * reads them); out[..., c] = act(ab[..., c]) * sigmoid(ab[..., C + c]) + res[..., c]  (res may be NULL).
+ * Supported: Cin <= 128, 2C <= 128, channel counts multiples of 4; otherwise LVAE_EINVAL (compose lvae_conv2d_f32 +
+ * lvae_gate_fwd_f32 instead). */
+int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream);
+
 /* Weight / bias gradient of the convolution described by `d` (d->y is unused, d->w gives only the strides):
  *   dw[tap,k,n] += sum_{n,oh,ow} T(x)[n,ih,iw,k] * dy[n,oh,ow,n]     db[n] += sum dy[..,n]
  * written with the strides d->w_stap/w_sk/w_sn into `dw` (accumulating). Deterministic: split-K partial slabs

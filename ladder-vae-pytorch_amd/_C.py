@@ -39,6 +39,7 @@ SIGNATURES = {
     'lvae_abi_version': (C.c_int, []),
     'lvae_last_error': (C.c_char_p, []),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv1x1_gate_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),

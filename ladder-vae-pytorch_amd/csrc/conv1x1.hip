@@ -1,0 +1,234 @@
+// Pointwise (1x1, stride 1) convolution for K = Cin <= 128, N = Cout <= 128: GateLayer2d's 64->128 conv, MergeLayer's
+// 128->64 conv (channel concat read from two tensors) and their dgrads.
+//
+// With K <= 128 there is nothing to pipeline over: the generic K-staged kernel spends its time in 2-4 dependent
+// load -> barrier -> MFMA round trips (measured 32 us for a layer whose MFMA floor is 7 us). Here a workgroup stages its
+// whole A tile (BM pixels x K) and the whole weight matrix in ONE batch of loads, runs all MFMAs, and writes the tile
+// through LDS with 16-byte row stores. Optional fused epilogue for the gate (lib/nn.py:121-126 + the residual add of
+// lib/nn.py:99): with N = 2C, out = act(y[:, :C]) * sigmoid(y[:, C:]) + res, written next to (or instead of) y.
+//
+// 4 waves as 2(M) x 2(N); wave wn owns columns {ni*64 + wn*32 + lane} (ni = 0,1), so for the gate the a- and b-halves of
+// a channel sit in the same lane.
+#include "lvae_common.h"
+
+namespace lvae {
+
+struct PwArgs {
+  lvae_conv_desc d;
+  int M, K, ohw;
+  const float* gate_res;  // [M][N/2] or null
+  float* gate_out;        // [M][N/2] or null (null: plain convolution)
+  int gate_act;
+};
+
+template <int BM, int KT, int NT, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
+  constexpr int LDA = KT + 4;
+  constexpr int K4 = KT / 4;
+  constexpr int WMT = BM / 2, MI = WMT / 32, NI = NT / 64;
+  constexpr int LDO = NT + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;             // [BM][LDA]
+  float* Bs = smem + BM * LDA;  // k-contig: [NT][LDA] ; n-contig: [KT][NT]
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const int K = a.K, N = d.Cout;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- one batch: A tile (two-pointer concat) and the weight matrix; clamped addresses, no exec-mask regions
+  constexpr int APT = BM * K4 / 256;  // float4 of A per thread
+  constexpr int BPT = NT * K4 / 256;  // float4 of B per thread (both layouts hold KT*NT floats)
+  f32x4 av[APT], bv[BPT];
+#pragma unroll
+  for (int u = 0; u < APT; ++u) {
+    const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
+    const int m = m0 + r;
+    const bool ok = (m < a.M) & (k < K);
+    const bool first = k < d.C1;
+    const float* src = first ? d.x : d.x2;
+    const size_t off = ok ? (size_t)m * (first ? d.C1 : d.C2) + (first ? k : k - d.C1) : 0;
+    const f32x4 v = *reinterpret_cast<const f32x4*>((ok ? src : d.x) + off);
+    av[u] = ok ? v : zero4;
+  }
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const int idx = t + 256 * u;
+    if (B_KCONTIG) {
+      const int n = idx / K4, k = (idx - n * K4) * 4;
+      const bool ok = (n < N) & (k < K);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + (ok ? (int64_t)n * d.w_sn + k : 0));
+      bv[u] = ok ? v : zero4;
+    } else {
+      const int k = idx / (NT / 4), n = (idx - k * (NT / 4)) * 4;
+      const bool ok = (k < K) & (n < N);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d.w + (ok ? (int64_t)k * d.w_sk + n : 0));
+      bv[u] = ok ? v : zero4;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < APT; ++u) {
+    const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
+    f32x4 v = av[u];
+    if (d.in_scale && m0 + r < a.M && k < K) {
+      v = v * *reinterpret_cast<const f32x4*>(d.in_scale + k) + *reinterpret_cast<const f32x4*>(d.in_shift + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.in_act);
+    }
+    *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
+  }
+#pragma unroll
+  for (int u = 0; u < BPT; ++u) {
+    const int idx = t + 256 * u;
+    if (B_KCONTIG) {
+      const int n = idx / K4, k = (idx - n * K4) * 4;
+      *reinterpret_cast<f32x4*>(Bs + n * LDA + k) = bv[u];
+    } else {
+      const int k = idx / (NT / 4), n = (idx - k * (NT / 4)) * 4;
+      *reinterpret_cast<f32x4*>(Bs + k * NT + n) = bv[u];
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#pragma unroll
+  for (int kk = 0; kk < KT; kk += 8) {
+    f32x4 af[MI], bf[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(As + (wm * WMT + mi * 32 + li) * LDA + kk + 4 * lh);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = ni * 64 + wn * 32 + li;
+      if (B_KCONTIG) {
+        bf[ni] = *reinterpret_cast<const f32x4*>(Bs + col * LDA + kk + 4 * lh);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[ni][j] = Bs[(kk + 4 * lh + j) * NT + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+  }
+  __syncthreads();  // operands are dead: reuse LDS as the output staging tile [BM][LDO]
+
+  float* Os = smem;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Os[(wm * WMT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + ni * 64 + wn * 32 + li] = acc[mi][ni][r];
+  __syncthreads();
+
+  if (a.gate_out != nullptr) {
+    // gate epilogue: C = N/2 channels; thread -> (pixel, 4 channels)
+    const int C = N >> 1, c4n = C >> 2;  // float4 per output pixel
+    for (int idx = t; idx < BM * c4n; idx += 256) {
+      const int r = idx / c4n, c = (idx - r * c4n) * 4;
+      const int m = m0 + r;
+      if (m >= a.M) continue;
+      f32x4 va = *reinterpret_cast<const f32x4*>(Os + r * LDO + c);
+      f32x4 vb = *reinterpret_cast<const f32x4*>(Os + r * LDO + C + c);
+      if (d.bias) {
+        va += *reinterpret_cast<const f32x4*>(d.bias + c);
+        vb += *reinterpret_cast<const f32x4*>(d.bias + C + c);
+      }
+      if (d.y) {
+        *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = va;
+        *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + C + c) = vb;
+      }
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = act_fwd(va[j], a.gate_act) * sigmoidf_(vb[j]);
+      if (a.gate_res) o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
+      *reinterpret_cast<f32x4*>(a.gate_out + (size_t)m * C + c) = o;
+    }
+  } else {
+    const int n4 = N >> 2;
+    for (int idx = t; idx < BM * n4; idx += 256) {
+      const int r = idx / n4, c = (idx - r * n4) * 4;
+      const int m = m0 + r;
+      if (m >= a.M) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * LDO + c);
+      if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + c);
+      if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(m / a.ohw) * N + c);
+      if (d.out_act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.out_act);
+      }
+      *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = v;
+    }
+  }
+}
+
+static bool al16p(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int KT, int NT, bool KC>
+static int launch_pw(const PwArgs& a, hipStream_t s) {
+  auto kern = conv1x1_kernel<BM, KT, NT, KC>;
+  constexpr size_t lds_in = (size_t)(BM * (KT + 4) + (KC ? NT * (KT + 4) : KT * NT)) * sizeof(float);
+  constexpr size_t lds_out = (size_t)BM * (NT + 4) * sizeof(float);
+  constexpr size_t lds = lds_in > lds_out ? lds_in : lds_out;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv1x1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM), dim3(256), lds, s, a);
+  LVAE_LAUNCH_CHECK("conv1x1");
+  return 0;
+}
+
+template <int KT, int NT, bool KC>
+static int pick_bm(const PwArgs& a, hipStream_t s) {
+  return (a.M >= 128 * 192) ? launch_pw<128, KT, NT, KC>(a, s) : launch_pw<64, KT, NT, KC>(a, s);
+}
+
+// -1000: not eligible (the caller uses the generic kernel)
+int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s) {
+  const int K = d->C1 + d->C2, N = d->Cout;
+  if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W) return -1000;
+  if (K > 128 || N > 128 || d->C1 % 4 || d->C2 % 4 || N % 4 || (gate_out && N % 8)) return -1000;
+  if (!al16p(d->x) || !al16p(d->x2) || !al16p(d->w) || !al16p(d->y) || !al16p(d->bias) || !al16p(d->in_scale) ||
+      !al16p(d->in_shift) || !al16p(d->out_scale) || !al16p(gate_res) || !al16p(gate_out))
+    return -1000;
+  const bool kc = d->w_sk == 1 && d->w_sn % 4 == 0 && K % 4 == 0;
+  const bool nc = d->w_sn == 1 && d->w_sk % 4 == 0;
+  if (!kc && !nc) return -1000;
+  if (gate_out == nullptr && d->y == nullptr) return -1000;
+  PwArgs a;
+  a.d = *d;
+  a.M = d->N * d->H * d->W;
+  a.K = K;
+  a.ohw = d->H * d->W;
+  a.gate_res = gate_res;
+  a.gate_out = gate_out;
+  a.gate_act = gate_act;
+  const bool k64 = K <= 64, n64 = N <= 64;
+  if (nc) {
+    if (k64) return n64 ? pick_bm<64, 64, false>(a, s) : pick_bm<64, 128, false>(a, s);
+    return n64 ? pick_bm<128, 64, false>(a, s) : pick_bm<128, 128, false>(a, s);
+  }
+  if (k64) return n64 ? pick_bm<64, 64, true>(a, s) : pick_bm<64, 128, true>(a, s);
+  return n64 ? pick_bm<128, 64, true>(a, s) : pick_bm<128, 128, true>(a, s);
+}
+
+}  // namespace lvae

@@ -354,6 +354,7 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
 }
 
 int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s);
+int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -367,7 +368,9 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   LVAE_REQUIRE(d->y != nullptr, LVAE_EINVAL, "lvae_conv2d_f32: null y");
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
   if (!halo_off) {
-    const int hr = conv3x3_halo_try(d, (hipStream_t)stream);
+    int hr = conv3x3_halo_try(d, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+    hr = conv1x1_try(d, nullptr, nullptr, 0, (hipStream_t)stream);
     if (hr != -1000) return hr;
   }
   ConvArgs a;
@@ -392,4 +395,19 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   if (d->w_sn == 1 && w16 && d->Cout % 4 == 0 && d->w_sk % 4 == 0) return dispatch_tile<true, B_NCONTIG>(a, s);
   if (d->w_sk == 1 && w16 && a.Cin % 4 == 0 && d->w_sn % 4 == 0) return dispatch_tile<true, B_KCONTIG>(a, s);
   return dispatch_tile<true, B_SCALAR>(a, s);
+}
+
+// GateLayer2d forward fused with its 1x1 convolution and the residual add (lib/nn.py:118-126, 99):
+//   ab = conv1x1(T(x)) + bias  (written to d->y when non-null; needed by the backward)
+//   out[m, c] = act(ab[m, c]) * sigmoid(ab[m, C + c]) + res[m, c]
+extern "C" int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream) {
+  int rc = conv_desc_check(d, "lvae_conv1x1_gate_f32");
+  if (rc) return rc;
+  LVAE_REQUIRE(out != nullptr, LVAE_EINVAL, "lvae_conv1x1_gate_f32: null out");
+  LVAE_REQUIRE(d->Cout % 2 == 0, LVAE_EINVAL, "lvae_conv1x1_gate_f32: Cout must be 2*C");
+  rc = conv1x1_try(d, res, out, act, (hipStream_t)stream);
+  LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
+               "lvae_conv1x1_gate_f32: unsupported shape (needs a 1x1 stride-1 conv, Cin <= 128, Cout <= 128, channels %% 4 == 0, "
+               "16-byte aligned buffers); use lvae_conv2d_f32 + lvae_gate_fwd_f32");
+  return rc;
 }

@@ -89,6 +89,24 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     return y
 
 
+def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True):
+    """GateLayer2d forward: ab = conv1x1(x) + bias (returned when need_ab), out = act(a) * sigmoid(b) + res, one kernel.
+    Falls back to conv2d + gate_fwd when the fused kernel does not support the shape."""
+    _chk_nhwc(x, 'x')
+    N, H, W, _ = x.shape
+    Cn = g.Cout // 2
+    fused_ok = (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cin <= 128 and
+                g.Cout <= 128 and g.Cin % 4 == 0 and g.Cout % 8 == 0 and (g.s_co == 1 or g.s_ci == 1))
+    if not fused_ok:
+        ab = conv2d(x, weight, g, bias=bias)
+        return ab, gate_fwd(ab, res, act)
+    ab = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=x.device) if need_ab else None
+    out = torch.empty((N, H, W, Cn), dtype=torch.float32, device=x.device)
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV, bias, y=ab)
+    call('lvae_conv1x1_gate_f32', C.byref(d), ptr(res), ACT[act], ptr(out), stream_ptr())
+    return ab, out
+
+
 def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
     """Gradient w.r.t. the conv input (before any fused input transform). dy NHWC (N,OH,OW,Cout) -> (N,H,W,Cin).
     out_scale (N,Cin) multiplies the result per (sample, channel) (Dropout2d mask of the producer).

@@ -142,8 +142,7 @@ class ResBlockFn(Function):
         y2 = h
         ab = None
         if blk.gate is not None:
-            ab = K.conv2d(y2, blk.gate.weight, blk.gate.geom(), bias=blk.gate.bias)
-            out = K.gate_fwd(ab, x, act)
+            ab, out = K.conv1x1_gate(y2, blk.gate.weight, blk.gate.geom(), blk.gate.bias, x, act)
         else:
             out = K.add(y2, x)
         ctx.blk, ctx.training = blk, training

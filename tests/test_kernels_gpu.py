@@ -162,6 +162,20 @@ def test_bn_stats_and_affine_bwd(K, shape):
     assert rel(dg.cpu(), gamma.grad) < 1e-5 and rel(db.cpu(), beta.grad) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (2, 8, 2, 2), (70, 32, 8, 8)])
+def test_conv1x1_gate_fused(K, shape):
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x, res = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w, b = torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C), torch.randn(2 * C, generator=g)
+    ab = F.conv2d(x, w, b)
+    a_, b_ = ab.chunk(2, 1)
+    out = F.elu(a_) * torch.sigmoid(b_) + res
+    wp = packed_weight(w)
+    abd, outd = K.conv1x1_gate(nhwc(x), wp, K.ConvGeom(wp, 1, 0), b.cuda(), nhwc(res), 'elu')
+    assert rel(nchw(abd), ab) < 2e-6 and rel(nchw(outd), out) < 2e-6
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
