@@ -118,14 +118,16 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 
-// one wave per channel: lane k combines chunks k, k+64, ... (Chan et al., double), then a fixed xor-shuffle tree
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
-                                                         const float* gamma, const float* beta, float eps, float momentum,
-                                                         float* running_mean, float* running_var, float* scale,
-                                                         float* shift, float* mean_out, float* rstd_out) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+// one 256-thread block per channel: thread k combines chunks k, k+256, ... (Chan et al., double), then a fixed
+// xor-shuffle tree inside each wave and a fixed-order combine of the 4 wave results through LDS
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
+                                                          const float* gamma, const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* scale,
+                                                          float* shift, float* mean_out, float* rstd_out) {
+  __shared__ double part[4][3];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int k = lane; k < chunks; k += 64) {
+  for (int k = tid; k < chunks; k += 256) {
     const float* p = ws + (size_t)k * 4 * C;
     const double nb = p[3 * C + c];
     if (nb <= 0.0) continue;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const double nb = shfl_xor_d(n, o), mb = shfl_xor_d(mean, o), m2b = shfl_xor_d(m2, o);
-    // combine in a lane-order independent way: lower lane index is always the left operand
+    // lane-order independent: the lower lane index is always the left operand
     if ((lane & o) == 0) chan_combine(n, mean, m2, nb, mb, m2b);
     else {
       double n2 = nb, me2 = mb, mm2 = m2b;
@@ -143,7 +145,14 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
       n = n2; mean = me2; m2 = mm2;
     }
   }
-  if (lane != 0) return;
+  if (lane == 0) {
+    part[wv][0] = n;
+    part[wv][1] = mean;
+    part[wv][2] = m2;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  for (int w = 1; w < 4; ++w) chan_combine(n, mean, m2, part[w][0], part[w][1], part[w][2]);
   const double var = m2 / (double)M;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -256,11 +265,12 @@ __global__ __launch_bounds__(256) void affine_bwd_partial_kernel(const float* __
 }
 
 // coef layout (tail of ws): [2][C] = (mean g, mean g*xhat)
-__global__ __launch_bounds__(64) void affine_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
-                                                                 float* dgamma, float* dbeta, float* coef) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void affine_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
+                                                                  float* dgamma, float* dbeta, float* coef) {
+  __shared__ double part[4][2];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double a = 0.0, b = 0.0;
-  for (int k = lane; k < chunks; k += 64) {
+  for (int k = tid; k < chunks; k += 256) {
     a += ws[(size_t)k * 2 * C + c];
     b += ws[(size_t)k * 2 * C + C + c];
   }
@@ -269,7 +279,14 @@ __global__ __launch_bounds__(64) void affine_bwd_finalize_kernel(const float* __
     a += shfl_xor_d(a, o);
     b += shfl_xor_d(b, o);
   }
-  if (lane != 0) return;
+  if (lane == 0) {
+    part[wv][0] = a;
+    part[wv][1] = b;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+  b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   coef[c] = (float)(a / (double)M);
@@ -429,7 +446,7 @@ extern "C" int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const flo
   else
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(used), dim3(256), 0, s, x, M, C, rm.cols, rm.rpp, rpc, ws);
   LVAE_LAUNCH_CHECK("bn_partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, mean, rstd);
   LVAE_LAUNCH_CHECK("bn_finalize");
   return 0;
@@ -494,7 +511,7 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
       hipLaunchKernelGGL(affine_bwd_partial_kernel<1>, dim3(used), dim3(256), 0, s, dh, x, M, C, rm.cols, rm.rpp, rpc,
                          scale, shift, act, mean, rstd, ws);
     LVAE_LAUNCH_CHECK("affine_bwd_partial");
-    hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, used, C, M, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, ws, used, C, M, dgamma, dbeta, coef);
     LVAE_LAUNCH_CHECK("affine_bwd_finalize");
   }
   LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_bwd_f32: too many rows");
