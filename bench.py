@@ -49,8 +49,9 @@ def synth_batches(n, batch, seed):
 
 
 def conv_roofline(model, x):
-    """Instrumented eager step: HIP events around every lvae_conv2d_f32 launch (conv_igemm_kernel: forward and dgrad)
-    on the launch stream. Returns algorithmic FLOPs / measured time over all those launches."""
+    """Instrumented eager step: HIP events (recorded on the launch stream) around every fp32-MFMA conv launch
+    (lvae_conv2d_f32 = forward and dgrad, lvae_conv1x1_gate_f32). Launches are grouped by shape; the group with the
+    largest total time is the dominant kernel and gets the per-launch roofline record."""
     from lvae_amd import kernels as K
     from lvae_amd.engine import forward_pass
     rec = []
@@ -63,11 +64,13 @@ def conv_roofline(model, x):
         flops = 2.0 * d.N * d.OH * d.OW * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
         if d.gather == 1 and d.stride > 1:
             flops /= d.stride * d.stride  # taps that hit no input pixel are not algorithmic work
+        nbytes = 4.0 * (d.N * d.H * d.W * (d.C1 + d.C2) + d.N * d.OH * d.OW * d.Cout + d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
+        key = 'conv %dx%d s%d %d->%d @%dx%dx%d' % (d.KH, d.KW, d.stride, d.C1 + d.C2, d.Cout, d.N, d.OH, d.OW)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig(name, *args)
         e1.record()
-        rec.append((flops, e0, e1))
+        rec.append((key, flops, nbytes, e0, e1))
 
     K.call = timed_call
     try:
@@ -77,9 +80,28 @@ def conv_roofline(model, x):
         torch.cuda.synchronize()
     finally:
         K.call = orig
-    tot_f = sum(r[0] for r in rec)
-    tot_ms = sum(r[1].elapsed_time(r[2]) for r in rec)
-    return tot_f, tot_ms, len(rec)
+    groups = {}
+    for key, f, nb, e0, e1 in rec:
+        g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += f
+        g[2] += nb
+        g[3] += e0.elapsed_time(e1)
+    dom = max(groups.items(), key=lambda kv: kv[1][3])
+    fam_f = sum(g[1] for g in groups.values())
+    fam_ms = sum(g[3] for g in groups.values())
+    return dom, fam_f, fam_ms, len(rec)
+
+
+def pmc_traffic(dom_key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/r01_pmc/hbm_traffic.json);
+    only the shape that was actually profiled (3x3 64->64 @256x16x16, conv3x3_halo_kernel<128,64,*> on 512 workgroups)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc', 'hbm_traffic.json')
+    if dom_key != 'conv 3x3 s1 64->64 @256x16x16' or not os.path.exists(path):
+        return None
+    ks = json.load(open(path))['kernels']
+    vals = [v['hbm_bytes_per_launch'] for k, v in ks.items() if k.startswith('conv3x3_halo_kernel<128, 64') and k.endswith('@512 workgroups')]
+    return sum(vals) / len(vals) if vals else None
 
 
 def cpu_baseline(cfg, batch, steps):
@@ -189,12 +211,17 @@ def main():
             'neg_elbo': -elbo, 'loss': loss,
         }
     if rank == 0 and not args.no_roofline:
-        f, ms_conv, n = conv_roofline(model, ring[0])
-        ach = f / (ms_conv * 1e-3) / 1e12
-        line['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s',
-                            'frac': ach / PEAK_MFMA_F32, 'traffic': None, 'kernel': 'fp32-MFMA conv kernels: conv3x3_halo, conv1x1, conv_igemm (all forward + dgrad launches)',
-                            'launches': n, 'avg_launch_us': ms_conv * 1e3 / n, 'flops_per_step': f,
-                            'conv_ms_per_step': ms_conv}
+        (dkey, (dn, dflops, dbytes, dms)), fam_f, fam_ms, n = conv_roofline(model, ring[0])
+        ach = dflops / (dms * 1e-3) / 1e12
+        line['roofline'] = {
+            'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32,
+            'traffic': pmc_traffic(dkey),
+            'kernel': 'conv3x3_halo_kernel (forward + dgrad launches of: %s)' % dkey,
+            'launches_per_step': dn, 'avg_launch_us': dms * 1e3 / dn, 'flops_per_launch': dflops / dn,
+            'algorithmic_bytes_per_launch': dbytes / dn,
+            'all_conv_fwd_dgrad': {'launches_per_step': n, 'flops_per_step': fam_f, 'ms_per_step': fam_ms,
+                                   'achieved': fam_f / (fam_ms * 1e-3) / 1e12, 'frac': fam_f / (fam_ms * 1e-3) / 1e12 / PEAK_MFMA_F32},
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline on %d host cores ...' % host_cores())
         line['cpu_baseline'] = cpu_baseline(CIFAR15, 32, 3)
