@@ -173,6 +173,17 @@ int lvae_dmol_ll_fwd_f32(const float* l, const float* x, int32_t N, int32_t HW, 
  * u_mix [N,HW,nmix], u_log [N,HW,3] uniforms in (1e-5, 1-1e-5); sample [N,HW,3] in [0,1]. */
 int lvae_dmol_sample_f32(const float* l, const float* u_mix, const float* u_log, int32_t N, int32_t HW, int32_t nmix,
                          float* sample, void* stream);
+/* Gaussian head — lib/likelihoods.py:81-114 + log_normal :391-411. params [N,P,2C] (P = H*W; mean = channels [0,C),
+ * logvar = [C,2C)), x / eps / sample [N,P,C]. sample = mean + exp(logvar/2)*eps; ll[n] = sum -0.5((x-mean)^2/var + logvar + log 2pi).
+ * dll_dparams [N,P,2C] optional. */
+int lvae_gaussian_fwd_f32(const float* params, const float* x, const float* eps, int32_t N, int64_t P, int32_t C,
+                          float* sample, float* ll, float* dll_dparams, void* stream);
+/* Discretized logistic head (256 bins) — lib/likelihoods.py:117-180 + log_discretized_logistic :233-288 and the sampler
+ * logistic_rsample lib/stochastic.py:115-138. raw [N,P,2C] conv output; mean = raw_mean + 0.5, logscale = max(raw_ls - 1, -7)
+ * (both [N,P,C], optional outputs); u uniforms in (1e-7, 1-1e-7); x is rescaled by 255/256 + 1/512 inside (:172).
+ * dll_draw [N,P,2C] optional: gradient w.r.t. the RAW conv output. */
+int lvae_discr_logistic_fwd_f32(const float* raw, const float* x, const float* u, int32_t N, int64_t P, int32_t C, float* mean,
+                                float* logscale, float* sample, float* ll, float* dll_draw, void* stream);
 /* out[n, i] = g[n] * a[n, i]  (chain rule through a per-sample scalar; backward of the two heads above) */
 int lvae_scale_per_sample_f32(const float* a, const float* g, int32_t N, int64_t P, float* out, void* stream);
 

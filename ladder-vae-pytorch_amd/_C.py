@@ -59,6 +59,8 @@ SIGNATURES = {
     'lvae_dmol_workspace': (_Z, [_I, _I]),
     'lvae_dmol_ll_fwd_f32': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'lvae_dmol_sample_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'lvae_gaussian_fwd_f32': (C.c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P]),
+    'lvae_discr_logistic_fwd_f32': (C.c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P]),
     'lvae_scale_per_sample_f32': (C.c_int, [_P, _P, _I, _L, _P, _P]),
     'lvae_upsample2x_fwd_f32': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     'lvae_upsample2x_bwd_f32': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),

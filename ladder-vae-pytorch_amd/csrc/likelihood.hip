@@ -206,6 +206,86 @@ __global__ __launch_bounds__(256) void dmol_sample_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Gaussian head (lib/likelihoods.py:81-114, log_normal :391-411). params [N][P][2C] = (mean | logvar) per pixel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_fwd_kernel(const float* __restrict__ params, const float* __restrict__ x,
+                                                            const float* __restrict__ eps, int64_t P, int C, float* sample,
+                                                            float* ll, float* dll) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  const int64_t per = P * C;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) {
+    const int64_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const size_t pb = ((size_t)n * P + pix) * 2 * C;
+    const float mean = params[pb + c], lv = params[pb + C + c];
+    if (sample) sample[(size_t)n * per + i] = mean + expf(0.5f * lv) * eps[(size_t)n * per + i];
+    if (x) {
+      const float d = x[(size_t)n * per + i] - mean, iv = expf(-lv);
+      acc += -0.5f * (d * d * iv + lv + 1.8378770664093453f);  // log(2*pi)
+      if (dll) {
+        dll[pb + c] = d * iv;
+        dll[pb + C + c] = -0.5f * (1.f - d * d * iv);
+      }
+    }
+  }
+  if (x) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ll[n] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Discretized logistic head (lib/likelihoods.py:117-180, log_discretized_logistic :233-288), 256 bins.
+// raw [N][P][2C] = (mean_raw | log_scale_raw); outputs mean = mean_raw + 0.5, logscale = max(ls_raw - 1, -7).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void discr_logistic_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ x,
+                                                                  const float* __restrict__ u, int64_t P, int C,
+                                                                  float* mean_out, float* ls_out, float* sample, float* ll,
+                                                                  float* dll) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  const int64_t per = P * C;
+  const float nb = 256.f;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) {
+    const int64_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const size_t pb = ((size_t)n * P + pix) * 2 * C, oi = (size_t)n * per + i;
+    const float mean = raw[pb + c] + 0.5f;
+    const float ls_raw = raw[pb + C + c] - 1.f;
+    const float ls = fmaxf(ls_raw, -7.f);
+    const float scale = expf(ls);
+    if (mean_out) mean_out[oi] = mean;
+    if (ls_out) ls_out[oi] = ls;
+    if (sample) {
+      const float uu = u[oi];
+      sample[oi] = fminf(fmaxf(mean + scale * (logf(uu) - logf(1.f - uu)), 0.f), 1.f);
+    }
+    if (x) {
+      const float xs = x[oi] * (255.f / 256.f) + 1.f / 512.f;
+      const float xq = floorf(xs * nb) / nb;
+      const bool has_plus = xq < (nb - 1.f) / nb, has_minus = xq >= 1.f / nb;
+      const float a = (xq + 1.f / nb - mean) / scale, b = (xq - mean) / scale;
+      const float sa = sigmoidf_(a), sb = sigmoidf_(b);
+      const float cp = has_plus ? sa : 1.f, cm = has_minus ? sb : 0.f;
+      const float prob = cp - cm + 1e-7f;
+      acc += logf(prob);
+      if (dll) {
+        const float da = has_plus ? sa * (1.f - sa) : 0.f, db = has_minus ? sb * (1.f - sb) : 0.f;
+        dll[pb + c] = -(da - db) / scale / prob;
+        dll[pb + C + c] = (ls_raw >= -7.f) ? -(a * da - b * db) / prob : 0.f;
+      }
+    }
+  }
+  if (x) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) ll[n] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_per_sample_kernel(const float* __restrict__ a, const float* __restrict__ g,
                                                                 int64_t P, int64_t total, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
@@ -264,5 +344,28 @@ extern "C" int lvae_scale_per_sample_f32(const float* a, const float* g, int32_t
   hipLaunchKernelGGL(scale_per_sample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, g, P,
                      total, out);
   LVAE_LAUNCH_CHECK("scale_per_sample");
+  return 0;
+}
+
+extern "C" int lvae_gaussian_fwd_f32(const float* params, const float* x, const float* eps, int32_t N, int64_t P, int32_t C,
+                                     float* sample, float* ll, float* dll_dparams, void* stream) {
+  LVAE_REQUIRE(params && N > 0 && P > 0 && C > 0, LVAE_EINVAL, "lvae_gaussian_fwd_f32: bad args");
+  LVAE_REQUIRE(!sample || eps, LVAE_EINVAL, "lvae_gaussian_fwd_f32: sample needs eps");
+  LVAE_REQUIRE(!x || ll, LVAE_EINVAL, "lvae_gaussian_fwd_f32: x given but ll is null");
+  hipLaunchKernelGGL(gaussian_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, params, x, eps, P, C, sample, ll,
+                     dll_dparams);
+  LVAE_LAUNCH_CHECK("gaussian_fwd");
+  return 0;
+}
+
+extern "C" int lvae_discr_logistic_fwd_f32(const float* raw, const float* x, const float* u, int32_t N, int64_t P, int32_t C,
+                                           float* mean, float* logscale, float* sample, float* ll, float* dll_draw,
+                                           void* stream) {
+  LVAE_REQUIRE(raw && N > 0 && P > 0 && C > 0, LVAE_EINVAL, "lvae_discr_logistic_fwd_f32: bad args");
+  LVAE_REQUIRE(!sample || u, LVAE_EINVAL, "lvae_discr_logistic_fwd_f32: sample needs uniforms");
+  LVAE_REQUIRE(!x || ll, LVAE_EINVAL, "lvae_discr_logistic_fwd_f32: x given but ll is null");
+  hipLaunchKernelGGL(discr_logistic_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, raw, x, u, P, C, mean, logscale,
+                     sample, ll, dll_draw);
+  LVAE_LAUNCH_CHECK("discr_logistic_fwd");
   return 0;
 }

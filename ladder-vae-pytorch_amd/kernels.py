@@ -285,6 +285,30 @@ def dmol_sample(l, u_mix, u_log):
     return s
 
 
+def gaussian_fwd(params, x, eps, need_grad):
+    """params (N,H,W,2C); x, eps (N,H,W,C). Returns sample, ll | None, dll_dparams | None."""
+    N, H, W, C2 = params.shape
+    Cn = C2 // 2
+    sample = torch.empty((N, H, W, Cn), dtype=torch.float32, device=params.device)
+    ll = torch.empty((N,), dtype=torch.float32, device=params.device) if x is not None else None
+    dll = torch.empty_like(params) if (need_grad and x is not None) else None
+    call('lvae_gaussian_fwd_f32', ptr(params), ptr(x), ptr(eps), N, H * W, Cn, ptr(sample), ptr(ll), ptr(dll), stream_ptr())
+    return sample, ll, dll
+
+
+def discr_logistic_fwd(raw, x, u, need_grad):
+    """raw (N,H,W,2C); x, u (N,H,W,C). Returns mean, logscale, sample, ll | None, dll_draw | None."""
+    N, H, W, C2 = raw.shape
+    Cn = C2 // 2
+    mk = lambda: torch.empty((N, H, W, Cn), dtype=torch.float32, device=raw.device)
+    mean, ls, sample = mk(), mk(), mk()
+    ll = torch.empty((N,), dtype=torch.float32, device=raw.device) if x is not None else None
+    dll = torch.empty_like(raw) if (need_grad and x is not None) else None
+    call('lvae_discr_logistic_fwd_f32', ptr(raw), ptr(x), ptr(u), N, H * W, Cn, ptr(mean), ptr(ls), ptr(sample), ptr(ll), ptr(dll),
+         stream_ptr())
+    return mean, ls, sample, ll, dll
+
+
 def scale_per_sample(a, g):
     N = a.shape[0]
     out = torch.empty_like(a)

@@ -51,14 +51,43 @@ class DiscretizedLogisticMixLikelihood(LikelihoodModule):
 
 
 class GaussianLikelihood(LikelihoodModule):
+    """lib/likelihoods.py:81-114: conv -> (mean, logvar); sample = mean + exp(logvar/2) * eps."""
+
     def __init__(self, ch_in, color_channels):
         super().__init__()
-        raise NotImplementedError("likelihood 'gaussian' (lib/likelihoods.py:81-114) is not on the BASELINE hot path and "
-                                  "has no HIP kernel yet (SURVEY.md §8f rank 4)")
+        self.color_channels = color_channels
+        self.parameter_net = Conv2dParams(ch_in, 2 * color_channels, 3, padding=1)
+
+    def forward(self, input_, x, noise):
+        p = self.parameter_net(input_)
+        N, H, W, _ = p.shape
+        eps = noise.normal((N, H, W, self.color_channels), p.device)
+        ll, sample = ops.GaussianFn.apply(p, x, eps)
+        if x is None:
+            ll = None
+        mean, lv = p[..., :self.color_channels], p[..., self.color_channels:]
+        return ll, {'mean': mean, 'mode': mean, 'sample': sample, 'params': {'mean': mean, 'logvar': lv}}
 
 
 class DiscretizedLogisticLikelihood(LikelihoodModule):
+    """lib/likelihoods.py:117-180 (256 bins, log_scale_bias -1, clamp -7, mean + 0.5)."""
+
+    log_scale_bias = -1.
+
     def __init__(self, ch_in, color_channels, n_bins, double=False):
         super().__init__()
-        raise NotImplementedError("likelihood 'discr_log' (lib/likelihoods.py:117-180) is not on the BASELINE hot path and "
-                                  "has no HIP kernel yet (SURVEY.md §8f rank 4)")
+        if n_bins != 256 or double:
+            raise NotImplementedError("the discretized-logistic kernel is built for 256 bins in single precision")
+        self.n_bins = n_bins
+        self.color_channels = color_channels
+        self.parameter_net = Conv2dParams(ch_in, 2 * color_channels, 3, padding=1)
+
+    def forward(self, input_, x, noise):
+        raw = self.parameter_net(input_)
+        N, H, W, _ = raw.shape
+        # logistic_rsample draws uniform_(1e-7, 1-1e-7) with the shape of the mean, NCHW (lib/stochastic.py:131-132)
+        u = noise.uniform((N, H, W, self.color_channels), 1e-7, 1 - 1e-7, raw.device, channel_last=False)
+        ll, mean, ls, sample = ops.DiscrLogisticFn.apply(raw, x, u)
+        if x is None:
+            ll = None
+        return ll, {'mean': mean, 'mode': mean, 'sample': sample, 'params': {'mean': mean, 'logscale': ls}}

@@ -294,6 +294,42 @@ class BernoulliFn(Function):
         return K.scale_per_sample(dll, _c(g_ll)), None, None
 
 
+class GaussianFn(Function):
+    """lib/likelihoods.py:81-114: returns ll (N,) [differentiable w.r.t. params] and the reparameterised sample."""
+
+    @staticmethod
+    def forward(ctx, params, x, eps):
+        sample, ll, dll = K.gaussian_fwd(params, x, eps, True)
+        ctx.save_for_backward(dll)
+        ctx.mark_non_differentiable(sample)
+        if ll is None:
+            ll = torch.zeros((params.shape[0],), device=params.device)
+        return ll, sample
+
+    @staticmethod
+    def backward(ctx, g_ll, g_sample):
+        (dll,) = ctx.saved_tensors
+        return (K.scale_per_sample(dll, _c(g_ll)) if dll is not None else None), None, None
+
+
+class DiscrLogisticFn(Function):
+    """lib/likelihoods.py:117-180: returns ll (N,), mean, logscale, sample (the last three carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, raw, x, u):
+        mean, ls, sample, ll, dll = K.discr_logistic_fwd(raw, x, u, True)
+        ctx.save_for_backward(dll)
+        ctx.mark_non_differentiable(mean, ls, sample)
+        if ll is None:
+            ll = torch.zeros((raw.shape[0],), device=raw.device)
+        return ll, mean, ls, sample
+
+    @staticmethod
+    def backward(ctx, g_ll, g_mean, g_ls, g_sample):
+        (dll,) = ctx.saved_tensors
+        return (K.scale_per_sample(dll, _c(g_ll)) if dll is not None else None), None, None
+
+
 class DmolFn(Function):
     """lib/likelihoods.py:227-230 + 291-382: ll (N,) from params (N,H,W,100) and x (N,H,W,3) in [0,1]."""
 

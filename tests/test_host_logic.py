@@ -60,8 +60,6 @@ def test_geometry_helpers_and_argument_checks():
         make(dropout=None)  # reference: nn.Dropout2d(None) in 'bacdbacd'
     with pytest.raises(ValueError):
         make(res_block_type='abcd')
-    with pytest.raises(NotImplementedError):
-        make(likelihood_form='gaussian')
 
 
 def test_noise_tape_layout_conversion():

@@ -246,6 +246,16 @@ def test_likelihood_golden_vectors(K):
     torch.testing.assert_close(nchw(s) * 2 - 1, g.t('dmol.sample'), rtol=1e-5, atol=1e-5)
 
 
+def test_discretized_logistic_golden_vector(K):
+    from conftest import load_golden
+    g = load_golden('ops')
+    mean, ls, x = g.t('dlog.mean'), g.t('dlog.ls'), g.t('dlog.x')
+    raw = torch.cat((mean - 0.5, ls + 1.0), dim=1)   # the kernel applies mean + 0.5 and logscale - 1 itself
+    m, l, smp, ll, dll = K.discr_logistic_fwd(nhwc(raw), nhwc(x), nhwc(torch.rand_like(x).clamp(1e-6, 1 - 1e-6)), True)
+    torch.testing.assert_close(ll.cpu(), g.t('dlog.ll'), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(nchw(l), ls.clamp(min=-7.), rtol=1e-6, atol=1e-6)
+
+
 def test_upsample_pad_crop(K):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(3, 8, 5, 6, generator=g, requires_grad=True)

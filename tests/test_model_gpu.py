@@ -7,7 +7,8 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-HIP_CASES = ['tiny_mnist', 'tiny_cifar', 'tiny_eval', 'tiny_cabdcabd', 'tiny_bacdbac', 'tiny_nobn_selu']
+HIP_CASES = ['tiny_mnist', 'tiny_cifar', 'tiny_eval', 'tiny_cabdcabd', 'tiny_bacdbac', 'tiny_nobn_selu', 'tiny_gauss',
+             'tiny_discrlog']
 
 
 def build(g, training=True):
@@ -54,6 +55,13 @@ def test_forward_backward_matches_reference(name):
         # mode / sample are thresholded: allow the few pixels whose probability sits within rounding of the threshold
         assert (out['out_mode'].cpu() != ref['out_mode']).float().mean() < 1e-3
         assert (out['out_sample'].cpu() != ref['out_sample']).float().mean() < 1e-3
+    elif g.cfg['likelihood_form'] in ('gaussian', 'discr_log'):
+        second = 'logvar' if g.cfg['likelihood_form'] == 'gaussian' else 'logscale'
+        torch.testing.assert_close(out['out_mean'].cpu(), ref['out_mean'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out['out_mode'].cpu(), ref['out_mode'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out['out_sample'].cpu(), ref['out_sample'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out['likelihood_params']['mean'].cpu(), ref['likelihood_params.mean'], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(out['likelihood_params'][second].cpu(), ref['likelihood_params.' + second], rtol=1e-4, atol=1e-4)
     else:
         assert out['out_mean'] is None and out['out_mode'] is None
         torch.testing.assert_close(out['likelihood_params']['all_params'].cpu(), ref['likelihood_params.all_params'],
