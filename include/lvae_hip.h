@@ -216,6 +216,10 @@ int lvae_elbo_loss_fwd_f32(const float* ll, const float* kl_sep, const float* kl
                            float* elbo_sep, float* scalars, void* stream);
 int lvae_elbo_loss_bwd_f32(const float* g_loss, float beta, int32_t N, float* d_ll, float* d_kl_loss, void* stream);
 
+/* Importance-weighted bound — evaluate.py:30,86-87 (the loop is boilr's test_procedure: S forward passes, then
+ * logsumexp - log S). elbo [S,N] (sample-major) -> out[n] = log mean_s exp(elbo[s][n]). */
+int lvae_iw_logmeanexp_f32(const float* elbo, int32_t S, int32_t N, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser and norms over the flat parameter arena — torch.optim.Adamax at experiment_manager.py:76-81 and the
  * L2 loop at experiment_manager.py:346-350.

@@ -69,6 +69,7 @@ SIGNATURES = {
     'lvae_kl_bookkeeping_bwd_f32': (C.c_int, [_P, _I, _I, _F, _P, _P, _P, _P, _P]),
     'lvae_elbo_loss_fwd_f32': (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P]),
     'lvae_elbo_loss_bwd_f32': (C.c_int, [_P, _F, _I, _P, _P, _P]),
+    'lvae_iw_logmeanexp_f32': (C.c_int, [_P, _I, _I, _P, _P]),
     'lvae_adamax_step_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P]),
     'lvae_sumsq_workspace': (_Z, [_L]),
     'lvae_l2norm_f32': (C.c_int, [_P, _L, _P, _P, _Z, _P]),

@@ -197,6 +197,17 @@ __global__ __launch_bounds__(256) void elbo_loss_bwd_kernel(const float* g_loss,
   if (blockIdx.x == 0 && threadIdx.x == 0) d_kl_loss[0] = g * beta;
 }
 
+// importance-weighted bound: out[n] = logsumexp_s elbo[s][n] - log S   (evaluate.py / boilr test_procedure, restated)
+__global__ __launch_bounds__(256) void iw_logmeanexp_kernel(const float* __restrict__ elbo, int S, int N, float* out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) mx = fmaxf(mx, elbo[(size_t)s * N + n]);
+  double acc = 0.0;
+  for (int s = 0; s < S; ++s) acc += (double)expf(elbo[(size_t)s * N + n] - mx);
+  out[n] = mx + (float)log(acc) - logf((float)S);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Adamax over the flat arena (torch.optim.Adamax semantics) and L2 norm
 // ---------------------------------------------------------------------------------------------------------
@@ -411,5 +422,12 @@ extern "C" int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream
   LVAE_REQUIRE(counter != nullptr, LVAE_EINVAL, "lvae_counter_advance: null counter");
   hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, by);
   LVAE_LAUNCH_CHECK("counter_advance");
+  return 0;
+}
+
+extern "C" int lvae_iw_logmeanexp_f32(const float* elbo, int32_t S, int32_t N, float* out, void* stream) {
+  LVAE_REQUIRE(elbo && out && S > 0 && N > 0, LVAE_EINVAL, "lvae_iw_logmeanexp_f32: bad args");
+  hipLaunchKernelGGL(iw_logmeanexp_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, elbo, S, N, out);
+  LVAE_LAUNCH_CHECK("iw_logmeanexp");
   return 0;
 }

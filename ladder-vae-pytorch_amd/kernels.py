@@ -379,6 +379,13 @@ def elbo_loss_bwd(g_loss, beta, N):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+def iw_logmeanexp(elbo_sn):
+    S, N = elbo_sn.shape
+    out = torch.empty((N,), dtype=torch.float32, device=elbo_sn.device)
+    call('lvae_iw_logmeanexp_f32', ptr(elbo_sn), S, N, ptr(out), stream_ptr())
+    return out
+
+
 def adamax_step(p, g, exp_avg, exp_inf, mask, lr, beta1, beta2, eps, weight_decay, gscale, step_count):
     call('lvae_adamax_step_f32', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_inf), ptr(mask), p.numel(), lr, beta1, beta2, eps,
          weight_decay, ptr(gscale), step_count.data_ptr(), stream_ptr())

@@ -539,3 +539,15 @@ def adamax_step(params, grads, exp_avg, exp_inf, step, lr=3e-4, betas=(0.9, 0.99
         m.mul_(b1).add_(g, alpha=1 - b1)
         torch.maximum(u * b2, g.abs() + eps, out=u)
         p.addcdiv_(m, u, value=-lr / (1 - b1 ** step))
+
+
+def iw_log_likelihood(sd, cfg, x, tape, n_samples):
+    """Importance-weighted bound per image: S eval-mode forward passes, logsumexp(elbo_sep) - log S
+    (evaluate.py:30,86-87; the loop is boilr's test_procedure, restated)."""
+    elbos = []
+    with torch.no_grad():
+        for _ in range(n_samples):
+            mo = lvae_forward(sd, cfg, x, tape, training=False)
+            elbos.append(mo['ll'] - mo['kl_sep'])
+    e = torch.stack(elbos, 0)
+    return torch.logsumexp(e, 0) - math.log(n_samples), e.mean(0)
