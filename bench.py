@@ -142,6 +142,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' to rehearse N ranks on one GPU)")
     ap.add_argument('--sync-wgrad', action='store_true', help='keep weight-gradient kernels on the main stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -154,10 +155,11 @@ def main():
     from lvae_amd.optim import Adamax
     from lvae_amd.engine import TrainStep
 
-    rank, world, local = ldist.init_from_env('nccl')
+    rank, world, local = ldist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
+    local = local % max(1, torch.cuda.device_count())  # rehearsal: several ranks may share one device (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

@@ -23,7 +23,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
