@@ -171,6 +171,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WTileArgs a) {
       for (int r = 0; r < 16; ++r) acc[k][c][r] = 0.f;
 
   const int steps = (a.TH * a.halo_w) >> 1;
+  // the loader wave on the same SIMD issues dense VALU / memory work: let the MFMA wave win issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   __syncthreads();  // tile 0 is staged
   for (int it = 0; it < my_tiles; ++it) {
     const float* Xs = smem + (it & 1) * a.buf_floats;
