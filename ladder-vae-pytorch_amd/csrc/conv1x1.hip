@@ -72,9 +72,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
     const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
     f32x4 v = av[u];
     if (d.in_scale && m0 + r < a.M && k < K) {
-      v = v * *reinterpret_cast<const f32x4*>(d.in_scale + k) + *reinterpret_cast<const f32x4*>(d.in_shift + k);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.in_act);
+      v = act_fwd4(v * *reinterpret_cast<const f32x4*>(d.in_scale + k) + *reinterpret_cast<const f32x4*>(d.in_shift + k), d.in_act);
     }
     *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
   }
@@ -151,9 +149,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
         *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = va;
         *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + C + c) = vb;
       }
-      f32x4 o;
+      f32x4 o = act_fwd4(va, a.gate_act);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = act_fwd(va[j], a.gate_act) * sigmoidf_(vb[j]);
+      for (int j = 0; j < 4; ++j) o[j] *= sigmoidf_(vb[j]);
       if (a.gate_res) o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
       *reinterpret_cast<f32x4*>(a.gate_out + (size_t)m * C + c) = o;
     }
@@ -166,10 +164,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * LDO + c);
       if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + c);
       if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(m / a.ohw) * N + c);
-      if (d.out_act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.out_act);
-      }
+      v = act_fwd4(v, d.out_act);
       *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = v;
     }
   }

@@ -92,48 +92,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
   for (int q = 0; q < RING; ++q) load_b(q, breg[q]);
 
-  // ---- halo patch: every (pixel, 4 channels) once, transform fused, zeros outside the image / batch
+  // ---- halo patch: every (pixel, 4 channels) once, transform fused, zeros outside the image / batch.
+  // idx = t + 256u: the channel group c4 of a thread is the same for every element (256 % CIN4 == 0), so scale/shift
+  // are loaded once; loads use clamped addresses + select (no exec-mask regions).
   if (!(a.debug & 1)) {
     const int per_img = a.halo_h * a.halo_w;
     const int total = a.halo_px * CIN4;
-    for (int base = t; base < total; base += 256 * 8) {
+    const int c4 = (t % CIN4) * 4;
+    const bool c_ok = c4 < Cin;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (d.in_scale && c_ok) {
+      sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
+      sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
+    }
+    const float* xc = d.x + c4;
+    const int px0 = t / CIN4;
+    for (int base = 0; base < total; base += 256 * 8) {
       f32x4 v[8];
-      int dst[8];
+      unsigned okm = 0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int idx = base + 256 * u;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dst[u] = -1;
+        const int idx = base + t + 256 * u;
+        const int px = base / CIN4 + px0 + u * (256 / CIN4);
+        const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+        const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+        const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+        const bool ok = (idx < total) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & c_ok;
+        const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin) : 0u;  // < 2^31 floats (checked on the host)
+        v[u] = *reinterpret_cast<const f32x4*>(xc + off);
+        okm |= ok ? (1u << u) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + t + 256 * u;
         if (idx < total) {
-          const int px = idx / CIN4, c4 = (idx - px * CIN4) * 4;
-          const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
-          const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
-          const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
-          dst[u] = px * LDA + c4;
-          if (n < d.N && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && c4 < Cin) {
-            v[u] = *reinterpret_cast<const f32x4*>(d.x + ((size_t)(n * d.H + ih) * d.W + iw) * Cin + c4);
-            dst[u] |= 0x40000000;  // loaded from memory: apply the input transform
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if ((okm >> u) & 1u) {
+            w = v[u];
+            if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
           }
+          const int px = base / CIN4 + px0 + u * (256 / CIN4);
+          *reinterpret_cast<f32x4*>(As + px * LDA + c4) = w;
         }
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (dst[u] >= 0 && (dst[u] & 0x40000000)) {
-          dst[u] &= 0x3fffffff;
-          if (d.in_scale) {
-            const int c4 = dst[u] % LDA;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
-            f32x4 x = v[u] * sc + sh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = act_fwd(x[j], d.in_act);
-            v[u] = x;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<f32x4*>(As + dst[u]) = v[u];
     }
   }
   store_b(0, breg[0]);
@@ -200,25 +201,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
       for (int r = 0; r < 16; ++r)
         Os[(wm * WMT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
     __syncthreads();
+    // tile pixel p of a tile that covers whole rows / whole images is pixel (n0*H + oh0)*W + p of the tensor: the output
+    // pointer is linear in p (16 pixel rows per pass), only the image index needs a division (for N bound and dropout)
     const int c4 = (t & 15) * 4, col = co0 + c4;
-    const int thw = a.TH * a.TW;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (d.bias && col < d.Cout) bias = *reinterpret_cast<const f32x4*>(d.bias + col);  // Cout % 4 == 0 on this path
+    if (col < d.Cout) {
+      f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+      if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);  // Cout % 4 == 0 on this path
+      const int p0 = t >> 4;
+      float* yp = d.y + ((size_t)(n0 * d.H + oh0) * d.W + p0) * d.Cout + col;
+      const float* op = Os + p0 * LDO + c4;
+      const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);  // pixels of images that exist
 #pragma unroll
-    for (int q = 0; q < BM / 16; ++q) {
-      const int p = (t >> 4) + 16 * q;
-      if (p >= tile_px || col >= d.Cout) continue;
-      const int img = fastdiv(p, a.m_thw), rr = p - img * thw;
-      const int n = n0 + img;
-      if (n >= d.N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Os + p * LDO + c4) + bias;
-      if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
-      if (d.out_act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], d.out_act);
+      for (int q = 0; q < BM / 16; ++q) {
+        const int p = p0 + 16 * q;
+        if (p < nvalid) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias;
+          if (d.out_scale) {
+            const int n = n0 + fastdiv(p, a.m_thw);
+            v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
+          }
+          v = act_fwd4(v, d.out_act);
+          *reinterpret_cast<f32x4*>(yp + (size_t)q * 16 * d.Cout) = v;
+        }
       }
-      // tile pixels of one image are contiguous in memory: (oh0*W + rr) since TW == W
-      *reinterpret_cast<f32x4*>(d.y + ((size_t)(n * d.H + oh0) * d.W + rr) * d.Cout + col) = v;
     }
   }
 }
@@ -279,6 +284,7 @@ int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
   const int Cin = d->C1;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return kHaloNotEligible;
   if (Cin > 64 || Cin % 4 != 0 || !al16(d->x) || !al16(d->w) || d->w_stap % 4 != 0) return kHaloNotEligible;
+  if ((int64_t)d->N * d->H * d->W * Cin >= ((int64_t)1 << 31)) return kHaloNotEligible;  // 32-bit element offsets in the halo loader
   if (d->in_scale && (!al16(d->in_scale) || !al16(d->in_shift))) return kHaloNotEligible;
   const bool kcontig = d->w_sk == 1 && d->w_sn % 4 == 0;
   const bool ncontig = d->w_sn == 1 && d->w_sk % 4 == 0 && d->Cout % 4 == 0;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WTileArgs a) {
           const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
           const int n = n0 + img, ih = oh0 + hy - a.pad, iw = hx - a.pad;
           const bool ok = (idx < x_f4) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & cx_ok;
-          const size_t off = ok ? ((size_t)(n * d.H + ih) * d.W + iw) * xcs + xco : 0;
+          const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * xcs + xco) : 0u;  // < 2^31 floats (host check)
           xv[u] = *reinterpret_cast<const f32x4*>(xsrc + off);
           xok |= ok ? (1u << u) : 0u;
         }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WTileArgs a) {
             const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
             const int n = n0 + img;
             const bool ok = (p < tile_px) & (n < d.N) & (co0 + c4 < d.Cout);
-            const size_t off = ok ? ((size_t)(n * d.H + oh0) * d.W + r) * d.Cout + co0 + c4 : 0;
+            const unsigned off = ok ? (unsigned)(((n * d.H + oh0) * d.W + r) * d.Cout + co0 + c4) : 0u;
             yv[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
             yok |= ok ? (1u << u) : 0u;
           }
@@ -118,11 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WTileArgs a) {
             f32x4 w = zero4;  // zero padding is inserted AFTER BatchNorm + activation
             if ((xok >> u) & 1u) {
               w = xv[u];
-              if (d.in_scale) {
-                w = w * sc + sh;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = act_fwd(w[j], d.in_act);
-              }
+              if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
             }
             *reinterpret_cast<f32x4*>(Xs + idx * 4) = w;
           }
@@ -241,6 +237,7 @@ static bool wtile_plan(const lvae_conv_desc* d, WTileArgs& a) {
   const int Cin = d->C1 + d->C2;
   const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
   if (!(k3 || k1) || d->stride != 1 || d->gather != LVAE_GATHER_CONV || d->OH != d->H || d->OW != d->W) return false;
+  if ((int64_t)d->N * d->H * d->W * (Cin > d->Cout ? Cin : d->Cout) >= ((int64_t)1 << 31)) return false;  // 32-bit element offsets
   if (Cin > 128 || (k3 && Cin > 64) || d->C1 % 4 != 0 || d->C2 % 4 != 0 || d->Cout % 4 != 0 || d->W % 2 != 0) return false;
   if (!al16w(d->x) || (d->x2 && !al16w(d->x2)) || (d->in_scale && (!al16w(d->in_scale) || !al16w(d->in_shift)))) return false;
   const int cin_t = cin_tile(Cin), pad = k3 ? 1 : 0;

@@ -43,6 +43,19 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
   }
 }
 
+// 4-wide activation with ONE wave-uniform branch for the two common cases (none, ELU) instead of a switch per element
+__device__ __forceinline__ f32x4 act_fwd4(f32x4 v, int act) {
+  if (act == LVAE_ACT_NONE) return v;
+  if (act == LVAE_ACT_ELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : __expf(v[j]) - 1.f;
+    return v;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], act);
+  return v;
+}
+
 // derivative w.r.t. the pre-activation x
 __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
