@@ -26,7 +26,11 @@ template <int BM, int CIN_T, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   constexpr int LDA = CIN_T + 4;   // A / k-contiguous B row stride (floats)
   constexpr int LDN = 64;          // n-contiguous B row stride
-  constexpr int WMT = BM / 2, MI = WMT / 32;
+  // BM = 32 (low-resolution layers): the 4 waves are 2 (co halves) x 2 (K groups); both K groups work on every stage
+  // concurrently (each takes half of the stage's 32 channels) and are summed through LDS in the epilogue: the dependent
+  // MFMA chain per wave halves (144 instead of 288) and the tile count doubles.
+  constexpr bool KG = BM == 32;
+  constexpr int WMT = KG ? 32 : BM / 2, MI = WMT / 32;
   constexpr int CIN4 = CIN_T / 4;
   constexpr int KS = 32;           // reduction channels per stage (half a tap at Cin = 64): keeps LDS <= 80 KB -> 2 WGs/CU
   constexpr int KS4 = KS / 4;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int wm = KG ? 0 : wave >> 1, kg = KG ? wave >> 1 : 0, wn = wave & 1, li = lane & 31, lh = lane >> 5;
 
   int bid = blockIdx.x;
   {
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     const int tapoff = (dh * a.halo_w + dw) * LDA + k0;
     const float* Bb = Bs + buf * BBUF;
 #pragma unroll
-    for (int kk = 0; kk < KS; kk += 8) {
+    for (int q8 = 0; q8 < (KG ? KS / 16 : KS / 8); ++q8) {
+      const int kk = (KG ? kg * (KS / 2) : 0) + q8 * 8;
       f32x4 af[MI], bf;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(As + hbase[mi] + tapoff + kk);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Os[(wm * WMT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
+        Os[kg * BM * LDO + (wm * WMT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
     __syncthreads();
     // tile pixel p of a tile that covers whole rows / whole images is pixel (n0*H + oh0)*W + p of the tensor: the output
     // pointer is linear in p (16 pixel rows per pass), only the image index needs a division (for N bound and dropout)
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
         const int p = p0 + 16 * q;
         if (p < nvalid) {
           f32x4 v = *reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias;
+          if (KG) v += *reinterpret_cast<const f32x4*>(op + BM * LDO + q * 16 * LDO);  // second K group
           if (d.out_scale) {
             const int n = n0 + fastdiv(p, a.m_thw);
             v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
@@ -271,7 +277,8 @@ static int launch_halo(HaloArgs a, hipStream_t s) {
     attr_set = true;
   }
   size_t lds = ((size_t)a.halo_px * (CIN_T + 4) + 2 * 64 * 36) * sizeof(float);
-  if (lds < (size_t)BM * 68 * sizeof(float)) lds = (size_t)BM * 68 * sizeof(float);  // epilogue staging tile
+  const size_t lds_out = (size_t)(BM == 32 ? 2 : 1) * BM * 68 * sizeof(float);  // epilogue staging tile(s)
+  if (lds < lds_out) lds = lds_out;
   const int img_groups = (a.d.N + a.NI - 1) / a.NI;
   a.ntn = (a.d.Cout + 63) / 64;
   hipLaunchKernelGGL(kern, dim3(img_groups * a.tiles_h * a.ntn), dim3(256), lds, s, a);
@@ -298,10 +305,10 @@ int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
   a.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
   static const int dbg = getenv("LVAE_HALO_DEBUG") ? atoi(getenv("LVAE_HALO_DEBUG")) : 0;  // phase-skip switch, profiling only
   a.debug = dbg;
-  int BM = M >= 128 * 192 ? 128 : 64;
-  if (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) {
-    BM = 64;
-    if (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) return kHaloNotEligible;
+  int BM = M >= 128 * 192 ? 128 : (M > 64 * 256 ? 64 : 32);
+  while (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) {
+    if (BM == 32) return kHaloNotEligible;
+    BM /= 2;
   }
   // n-contiguous weights take precedence when both hold (Cin == 1 cannot reach here)
   const bool kc = !ncontig;
@@ -309,8 +316,12 @@ int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
     if (cin_t == 64) return kc ? launch_halo<128, 64, true>(a, s) : launch_halo<128, 64, false>(a, s);
     return kc ? launch_halo<128, 32, true>(a, s) : launch_halo<128, 32, false>(a, s);
   }
-  if (cin_t == 64) return kc ? launch_halo<64, 64, true>(a, s) : launch_halo<64, 64, false>(a, s);
-  return kc ? launch_halo<64, 32, true>(a, s) : launch_halo<64, 32, false>(a, s);
+  if (BM == 64) {
+    if (cin_t == 64) return kc ? launch_halo<64, 64, true>(a, s) : launch_halo<64, 64, false>(a, s);
+    return kc ? launch_halo<64, 32, true>(a, s) : launch_halo<64, 32, false>(a, s);
+  }
+  if (cin_t == 64) return kc ? launch_halo<32, 64, true>(a, s) : launch_halo<32, 64, false>(a, s);
+  return kc ? launch_halo<32, 32, true>(a, s) : launch_halo<32, 32, false>(a, s);
 }
 
 }  // namespace lvae
