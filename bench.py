@@ -170,7 +170,7 @@ def main():
     arena = model.pack()
     ldist.broadcast_flat(arena.params)
     opt = Adamax(model, lr=3e-4)
-    allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
+    allreduce = ldist.GradAllReduce(arena.grads) if (world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1') else None
     step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce, async_wgrad=not args.sync_wgrad)
 
     torch.set_num_threads(host_cores())
@@ -229,7 +229,7 @@ def main():
         line['cpu_baseline'] = cpu_baseline(CIFAR15, 32, 3)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,7 +17,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('LVAE_FORCE_DIST') == '1'  # rehearse the collective path with a single rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -53,6 +54,7 @@ class GradAllReduce:
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = os.environ.get('LVAE_FORCE_DIST') == '1' and dist.is_initialized()
         self.buckets = bucket_slices(flat_grads.numel(), max(1, int(bucket_mb * (1 << 20) / 4)))
         self.on_gpu = flat_grads.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grads.device) if self.on_gpu else None
@@ -60,7 +62,7 @@ class GradAllReduce:
 
     def run(self):
         """Reduce all buckets; the caller's current stream waits for completion (no host sync)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if not self.on_gpu:
             for lo, hi in self.buckets:
@@ -76,5 +78,5 @@ class GradAllReduce:
 
 def broadcast_flat(flat, src=0, group=None):
     """Identical initial replicas: broadcast rank `src`'s flat parameter arena once."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get('LVAE_FORCE_DIST') == '1'):
         dist.broadcast(flat, src=src, group=group)

@@ -71,7 +71,7 @@ class TrainStep:
     def _capture(self, x):
         self.static_x = torch.empty_like(x)
         self.static_x.copy_(x)
-        fused = self.allreduce is None or self.allreduce.world == 1
+        fused = self.allreduce is None or (self.allreduce.world == 1 and not getattr(self.allreduce, 'force', False))
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
