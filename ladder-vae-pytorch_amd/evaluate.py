@@ -107,7 +107,8 @@ def main(argv=None):
     exp = LVAEExperiment(args=args)
     model = exp.model
     if args.checkpoint:
-        model.load_state_dict(torch.load(args.checkpoint, map_location='cpu'))
+        from .checkpoint import load_checkpoint
+        load_checkpoint(args.checkpoint, model)
     if args.ll:
         gen = torch.Generator().manual_seed(args.seed)
         if args.data_npz:

@@ -78,6 +78,7 @@ def build_parser():
     p.add_argument('--steps', type=int, default=0, help='stop after this many steps (0: --max-steps)')
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     p.add_argument('--log-every', type=int, default=100)
+    p.add_argument('--save-checkpoint', type=str, default='', help='write a reference-layout checkpoint here at the end')
     return p
 
 

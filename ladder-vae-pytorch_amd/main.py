@@ -29,6 +29,9 @@ def main(argv=None):
         raise SystemExit("datasets cannot be downloaded here: pass --synthetic or --data-npz FILE")
     model, opt = exp.model, exp.optimizer
     model.noise.seed ^= rank * 0x9E3779B9
+    if args.resume:
+        from .checkpoint import load_checkpoint
+        load_checkpoint(args.resume, model, opt)
     model.train()
     arena = model.pack()
     ldist.broadcast_flat(arena.params)
@@ -63,6 +66,9 @@ def main(argv=None):
             dt = time.time() - t0
             print(exp.train_log_str(m, step) + '   [{:.0f} img/s]'.format(seen / dt))
             t0, seen = time.time(), 0
+    if args.save_checkpoint and rank == 0:
+        from .checkpoint import save_checkpoint
+        save_checkpoint(args.save_checkpoint, model, opt)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
