@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 1
+#define LVAE_ABI_VERSION 2
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -70,8 +70,14 @@ typedef struct lvae_conv_desc {
   int32_t N, H, W, OH, OW, Cout;
   int32_t KH, KW, stride, pad;
   int32_t gather;        /* LVAE_GATHER_* */
+  void* workspace;       /* scratch for lvae_conv2d_f32 (transformed weights of the Winograd path) or NULL */
+  int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
 } lvae_conv_desc;
 
+/* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
+ * as Winograd F(2x2,3x3) on the fp32 MFMA (2.25x fewer multiplies; coefficients 0, +-1, +-1/2, result within a few ulp of
+ * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
+size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
 
 /* GateLayer2d forward fused with its 1x1 convolution and the residual add — lib/nn.py:118-126 and lib/nn.py:99.
@@ -97,6 +103,9 @@ int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, f
 /* Per-channel batch statistics of x [M,C] (M = N*H*W): writes
  *   scale[c] = gamma[c]*rstd[c], shift[c] = beta[c] - mean[c]*scale[c], mean[c], rstd[c]
  * and, when running_mean != NULL, updates running_mean/var with `momentum` (unbiased variance).
+ * Two launches (per-chunk partial sums, fixed-order finalize: bitwise reproducible, no float atomics). A single launch with a
+ * last-workgroup-done hand-off was measured and rejected: on the 8-XCD part every workgroup's agent-scope release/acquire
+ * writes back and invalidates its XCD's L2 (+20 us per launch).
  * workspace: lvae_bn_stats_workspace(M, C) bytes. */
 size_t lvae_bn_stats_workspace(int64_t M, int32_t C);
 int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
@@ -115,7 +124,7 @@ int lvae_affine_act_f32(const float* x, int64_t M, int32_t C, const float* scale
  *   bn_train: dgamma += sum g*xhat, dbeta += sum g, dx = scale*(g - mean(g) - xhat*mean(g*xhat))
  *   else    : dx = scale*g
  * then dx *= drop[n,c] (optional Dropout2d mask of the producer) and dx += add (optional residual gradient).
- * Two launches (reduce, apply); workspace lvae_bn_stats_workspace(M,C) bytes. */
+ * Three launches (partial sums, finalize, apply); workspace lvae_bn_stats_workspace(M,C) bytes. */
 int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t M, int32_t C, const float* scale,
                             const float* shift, int32_t act, int32_t bn_train, const float* mean, const float* rstd,
                             float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n, const float* add,

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
         ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-        ('gather', C.c_int32),
+        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
     ]
 
 
@@ -38,6 +38,7 @@ _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     'lvae_abi_version': (C.c_int, []),
     'lvae_last_error': (C.c_char_p, []),
+    'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv1x1_gate_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
@@ -92,8 +93,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype, fn.argtypes = res, args
-    if lib.lvae_abi_version() != 1:
-        raise LvaeHipError("liblvae_hip.so ABI version %d, expected 1" % lib.lvae_abi_version())
+    if lib.lvae_abi_version() != 2:
+        raise LvaeHipError("liblvae_hip.so ABI version %d, expected 2" % lib.lvae_abi_version())
     _lib = lib
     return lib
 

@@ -1,0 +1,343 @@
+// Winograd F(2x2, 3x3) for the large 3x3 / stride 1 / pad 1 convolutions (forward and dgrad), fp32 throughout.
+//
+// On gfx950 the fp32 MFMA runs at the fp32 vector rate, and these layers are bound by it. Winograd's
+// minimal filtering computes each 2x2 output block from a 4x4 input block with 16 instead of 36 multiplies per
+// (ci, co) pair: 2.25x less MFMA work, same fp32 data, transforms are exact +/- combinations (F(2,3) has only
+// 0, +-1, +-1/2 coefficients, so the extra rounding is a few ulp).
+//
+//   U[p] = G g G^T        (16 position matrices [Cout][Cin], made by wino_weight_kernel once per launch)
+//   V[p] = B^T d B        (input transform, in registers, straight from the LDS-resident halo patch)
+//   M[p] = V[p] * U[p]    (16 independent GEMMs over Cin on v_mfma_f32_32x32x2_f32)
+//   Y    = A^T M A        (inverse transform: lane-local, because accumulator register r of every position holds the same
+//                          (tile, co) element)
+//
+// Workgroup: 128 output pixels = 32 Winograd tiles x 64 output channels, 4 waves. Wave i owns row i of the 4x4 position
+// grid (positions 4i..4i+3) for all 32 tiles and all 64 channels: its share of the input transform needs only two rows of
+// the 4x4 pixel block (8 ds_read_b128 + 32 VALU per 8 channels) and feeds 32 MFMAs, so the vector ALU — which the fp32
+// MFMA shares its datapath with — stays almost idle. U fragments come straight from L2 (U is laid out so that one wave
+// load is 1 KB contiguous), which removes every barrier from the reduction loop except the four that publish the
+// 16-channel slices of the halo patch; those slices are fetched one ahead of the MFMAs that consume them.
+// The inverse transform is separable: each wave reduces its row to R[i][b] = sum_j M[i][j] A[j][b] lane-locally,
+// the four rows meet in LDS, and the store pass forms Y[a][b] = sum_i A[a][i] R[i][b] with bias/dropout/activation.
+#include <stdlib.h>
+
+#include "lvae_common.h"
+
+namespace lvae {
+
+struct WinoArgs {
+  lvae_conv_desc d;
+  const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, debug;
+  uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
+};
+
+// ---- weight transform: U[p] = (G g G^T)[p] with g[kh][kw] = w[tap(kh,kw)][k][n] (taps flipped for dgrad)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int64_t stap, int64_t sk, int64_t sn,
+                                                           int K, int N, int Npad, int flip, float* __restrict__ U) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Npad * 64) return;
+  // consecutive threads -> consecutive floats of one position slab [8][2][Npad][4]
+  const int e = idx & 3, n = (idx >> 2) % Npad, kq = (idx >> 2) / Npad;  // kq = k / 4
+  const int k = kq * 4 + e;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int tap = flip ? (2 - a) * 3 + (2 - b) : a * 3 + b;
+      g[a][b] = (n < N && k < K) ? w[tap * stap + (int64_t)k * sk + (int64_t)n * sn] : 0.f;
+    }
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+  const size_t slab = (size_t)Npad * 64;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float* dst = U + (size_t)(a * 4) * slab + idx;
+    dst[0] = t[a][0];
+    dst[slab] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    dst[2 * slab] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+    dst[3 * slab] = t[a][2];
+  }
+}
+
+constexpr int WLDA = 68;  // halo pixel stride (floats)
+constexpr int WLDO = 68;  // R row stride (floats)
+
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;  // [halo_px][WLDA]; reused as R[4][2][32][WLDO] by the epilogue
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.ntn;
+  const int tm = bid / a.ntn;
+  const int th_idx = tm % a.tiles_h, ig = tm / a.tiles_h;
+  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- halo patch in four 16-channel slices; slot = (pixel, float4 within the slice)
+  constexpr int SLOTS = 4;  // per thread and slice: halo_px <= 256 (checked by the launcher)
+  const int per_img = a.halo_h * a.halo_w;
+  const int hc4 = (t & 3) * 4;
+  unsigned hoff[SLOTS];   // global offset (floats) of the pixel, or ~0u when it is padding
+  int hlds[SLOTS];        // LDS offset (floats), or -1 when the slot does not exist
+#pragma unroll
+  for (int u = 0; u < SLOTS; ++u) {
+    const int px = (t >> 2) + 64 * u;
+    const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+    const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+    const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+    const bool ok = (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W);
+    hoff[u] = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * 64 + hc4) : ~0u;
+    hlds[u] = px < a.halo_px ? px * WLDA + hc4 : -1;
+  }
+  f32x4 hreg[SLOTS];
+  auto load_slice = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      const unsigned off = hoff[u] == ~0u ? 0u : hoff[u] + 16 * c;
+      hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+    }
+  };
+  auto store_slice = [&](int c) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+    if (d.in_scale) {
+      sc = *reinterpret_cast<const f32x4*>(d.in_scale + 16 * c + hc4);
+      sh = *reinterpret_cast<const f32x4*>(d.in_shift + 16 * c + hc4);
+    }
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      if (hlds[u] >= 0) {
+        f32x4 w = zero4;
+        if (hoff[u] != ~0u) {
+          w = hreg[u];
+          if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
+        }
+        *reinterpret_cast<f32x4*>(As + hlds[u] + 16 * c) = w;
+      }
+    }
+  };
+  load_slice(0);
+
+  // ---- this lane's Winograd tile -> top-left halo pixel; this wave's two pixel rows of the 4x4 block
+  int wt = li;
+  if (wt >= a.n_wt) wt = 0;  // unused tile slots compute on a valid address; their results are never stored
+  const int wimg = fastdiv(wt, a.m_wt_per_img), wr = wt - wimg * a.wt_per_img;
+  const int wty = fastdiv(wr, a.m_tiles_x), wtx = wr - wty * a.tiles_x;
+  // B^T rows: [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1]  ->  t = d[ra] + sgn * d[rb]
+  const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const float sgn = wave == 1 ? 1.f : -1.f;
+  const int pbase = (wimg * a.halo_h + 2 * wty) * a.halo_w + 2 * wtx;
+  const float* pa = As + (size_t)(pbase + ra * a.halo_w) * WLDA + 4 * lh;
+  const float* pb = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 4 * lh;
+
+  // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
+  const size_t slab = (size_t)a.Npad * 64;
+  const float* ub = a.U + (size_t)(4 * wave) * slab + ((size_t)lh * a.Npad + co0 + li) * 4;
+  const size_t kstep = (size_t)2 * a.Npad * 4;
+  f32x4 bf[2][4][2];
+  auto load_u = [&](int ks, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) bf[buf][j][h] = *reinterpret_cast<const f32x4*>(ub + j * slab + ks * kstep + h * 128);
+  };
+  load_u(0, 0);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.f;
+
+  store_slice(0);
+  load_slice(1);
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks + 1 < 8 && !(DBG & 1)) load_u(ks + 1, (ks + 1) & 1);
+    f32x4 tt[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 da = *reinterpret_cast<const f32x4*>(pa + c * WLDA + ks * 8);
+      const f32x4 db = *reinterpret_cast<const f32x4*>(pb + c * WLDA + ks * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tt[c][e] = __builtin_fmaf(sgn, db[e], da[e]);  // sgn = +-1: exact
+    }
+    f32x4 vv[4];
+    vv[0] = tt[0] - tt[2];
+    vv[1] = tt[1] + tt[2];
+    vv[2] = tt[2] - tt[1];
+    vv[3] = tt[1] - tt[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks & 1][j][h][e], acc[j][h], 0, 0, 0);
+    if ((ks & 1) && ks < 7 && !(DBG & 4)) {  // publish the next 16-channel slice, start fetching the one after
+      const int c = (ks + 1) >> 1;
+      store_slice(c);
+      if (c + 1 < 4) load_slice(c + 1);
+      __syncthreads();
+    }
+  }
+  __syncthreads();  // every wave is done with the halo patch: LDS becomes R[wave][b][tile][co]
+
+  // ---- R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]; accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh
+  float* Rs = smem;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float r0 = acc[0][h][r] + acc[1][h][r] + acc[2][h][r];
+      const float r1 = acc[1][h][r] - acc[2][h][r] - acc[3][h][r];
+      float* o = Rs + (size_t)((wave * 2) * 32 + tile) * WLDO + h * 32 + li;
+      o[0] = r0;
+      o[32 * WLDO] = r1;
+    }
+  __syncthreads();
+  {
+    const int c4 = (t & 15) * 4, col = co0 + c4;
+    if (col < d.Cout) {
+      f32x4 bias = zero4;
+      if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
+      const int thw = a.TH * a.TW;
+      const int nvalid = min(a.NI, d.N - n0) * thw;
+      float* yb = d.y + ((size_t)(n0 * d.H + oh0) * d.W) * d.Cout + col;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int p = (t >> 4) + 16 * q;
+        if (p < nvalid && !(DBG & 8)) {
+          const int img = fastdiv(p, a.m_thw), pr = p - img * thw;
+          const int oy = fastdiv(pr, a.m_tw), ox = pr - oy * a.TW;
+          const int tile = img * a.wt_per_img + (oy >> 1) * a.tiles_x + (ox >> 1);
+          const float* rp = Rs + (size_t)((ox & 1) * 32 + tile) * WLDO + c4;  // R[i][b = ox&1][tile]
+          const f32x4 R0 = *reinterpret_cast<const f32x4*>(rp);
+          const f32x4 R1 = *reinterpret_cast<const f32x4*>(rp + 64 * WLDO);
+          const f32x4 R2 = *reinterpret_cast<const f32x4*>(rp + 128 * WLDO);
+          const f32x4 R3 = *reinterpret_cast<const f32x4*>(rp + 192 * WLDO);
+          f32x4 v = (oy & 1) ? (R1 - R2 - R3) : (R0 + R1 + R2);
+          v = v + bias;
+          if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
+          v = act_fwd4(v, d.out_act);
+          *reinterpret_cast<f32x4*>(yb + (size_t)p * d.Cout) = v;
+        }
+      }
+    }
+  }
+}
+
+static bool al16w2(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+size_t conv3x3_wino_workspace(const lvae_conv_desc* d) {
+  const int ntn = (d->Cout + 63) / 64;
+  return (size_t)16 * ntn * 64 * 64 * sizeof(float);  // 16 position slabs [8][2][Npad][4]
+}
+
+bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
+  static const bool off = getenv("LVAE_DISABLE_WINO") != nullptr;  // A/B switch, profiling only
+  if (off) return false;
+  const int Cin = d->C1;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;
+  if (Cin != 64 || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->W > 128) return false;
+  if (!al16w2(d->x) || !al16w2(d->y) || !al16w2(d->bias) || !al16w2(d->in_scale) || !al16w2(d->in_shift) || !al16w2(d->out_scale)) return false;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 192;  // tuning switch
+  if (M < min_m || M * 64 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
+  return true;
+}
+
+// -1000: not eligible. `workspace` must hold conv3x3_wino_workspace(d) bytes (the transformed weights).
+int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (workspace == nullptr || !conv3x3_wino_eligible(d)) return -1000;
+  if (workspace_bytes < conv3x3_wino_workspace(d) || !al16w2(workspace)) return -1000;
+  const int Cin = d->C1;
+  WinoArgs a;
+  a.d = *d;
+  // tile: whole rows, even height, <= 128 pixels (32 Winograd tiles); whole images when several fit
+  int TH = 0;
+  for (int c = 2; c <= d->H; c += 2)
+    if (d->H % c == 0 && c * d->W <= 128) TH = c;
+  if (TH == 0) return -1000;
+  int NI = TH < d->H ? 1 : 128 / (TH * d->W);
+  if (NI < 1) NI = 1;
+  if (NI > d->N) NI = d->N;
+  a.TH = TH;
+  a.TW = d->W;
+  a.NI = NI;
+  a.tiles_h = d->H / TH;
+  a.halo_h = TH + 2;
+  a.halo_w = d->W + 2;
+  a.halo_px = NI * a.halo_h * a.halo_w;
+  if (a.halo_px > 256) return -1000;
+  a.tiles_x = d->W / 2;
+  a.wt_per_img = (TH / 2) * a.tiles_x;
+  a.n_wt = NI * a.wt_per_img;
+  static const int dbg = getenv("LVAE_WINO_DEBUG") ? atoi(getenv("LVAE_WINO_DEBUG")) : 0;  // phase-skip switches, profiling only
+  a.debug = dbg;
+  a.ntn = (d->Cout + 63) / 64;
+  a.Npad = a.ntn * 64;
+  a.m_thw = fastdiv_magic(TH * d->W);
+  a.m_tw = fastdiv_magic(d->W);
+  a.m_per_img = fastdiv_magic(a.halo_h * a.halo_w);
+  a.m_halo_w = fastdiv_magic(a.halo_w);
+  a.m_tiles_x = fastdiv_magic(a.tiles_x);
+  a.m_wt_per_img = fastdiv_magic(a.wt_per_img);
+  size_t lds = (size_t)a.halo_px * WLDA * sizeof(float);
+  const size_t lds_r = (size_t)4 * 2 * 32 * WLDO * sizeof(float);
+  if (lds < lds_r) lds = lds_r;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipSuccess;
+    for (const void* f : {(const void*)conv3x3_wino_kernel<0>, (const void*)conv3x3_wino_kernel<1>, (const void*)conv3x3_wino_kernel<2>,
+                          (const void*)conv3x3_wino_kernel<4>, (const void*)conv3x3_wino_kernel<8>, (const void*)conv3x3_wino_kernel<16>,
+                          (const void*)conv3x3_wino_kernel<15>})
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  float* U = static_cast<float*>(workspace);
+  a.U = U;
+  const int Npad = a.Npad;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * 64 + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
+                     d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
+  LVAE_LAUNCH_CHECK("wino_weight");
+  const int img_groups = (d->N + NI - 1) / NI;
+  const dim3 grid(img_groups * a.tiles_h * a.ntn);
+  switch (a.debug) {
+    case 1: hipLaunchKernelGGL(conv3x3_wino_kernel<1>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(conv3x3_wino_kernel<2>, grid, dim3(256), lds, s, a); break;
+    case 4: hipLaunchKernelGGL(conv3x3_wino_kernel<4>, grid, dim3(256), lds, s, a); break;
+    case 8: hipLaunchKernelGGL(conv3x3_wino_kernel<8>, grid, dim3(256), lds, s, a); break;
+    case 15: hipLaunchKernelGGL(conv3x3_wino_kernel<15>, grid, dim3(256), lds, s, a); break;
+    case 16: hipLaunchKernelGGL(conv3x3_wino_kernel<16>, grid, dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL(conv3x3_wino_kernel<0>, grid, dim3(256), lds, s, a);
+  }
+  LVAE_LAUNCH_CHECK("conv3x3_wino");
+  return 0;
+}
+
+}  // namespace lvae

@@ -354,6 +354,9 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
 }
 
 int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s);
+int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s);
+size_t conv3x3_wino_workspace(const lvae_conv_desc* d);
+bool conv3x3_wino_eligible(const lvae_conv_desc* d);
 int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -362,13 +365,20 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 using namespace lvae;
 
+extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
+  if (d == nullptr) return 0;
+  return conv3x3_wino_eligible(d) ? conv3x3_wino_workspace(d) : 0;
+}
+
 extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv2d_f32");
   if (rc) return rc;
   LVAE_REQUIRE(d->y != nullptr, LVAE_EINVAL, "lvae_conv2d_f32: null y");
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
   if (!halo_off) {
-    int hr = conv3x3_halo_try(d, (hipStream_t)stream);
+    int hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+    hr = conv3x3_halo_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;
     hr = conv1x1_try(d, nullptr, nullptr, 0, (hipStream_t)stream);
     if (hr != -1000) return hr;

@@ -10,6 +10,7 @@ namespace lvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 void set_error(const char* fmt, ...);
 

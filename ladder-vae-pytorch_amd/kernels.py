@@ -72,6 +72,13 @@ def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, b
     return d
 
 
+def _conv_ws(d, device):
+    need = _C.load().lvae_conv2d_workspace(C.byref(d))
+    if need:
+        ws = workspace(need, device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+
+
 def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None):
     """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC."""
     _chk_nhwc(x, 'x')
@@ -85,6 +92,7 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     y = torch.empty((N, OH, OW, g.Cout), dtype=torch.float32, device=x.device)
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
+    _conv_ws(d, x.device)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return y
 
@@ -119,6 +127,7 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
     d = _desc(g, weight, dy, None, N, OH, OW, H, W, b - a, g.s_co, g.s_ci,
               GATHER_CONV if g.transposed else GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     d.w = ptr(weight) + 4 * a * g.s_ci
+    _conv_ws(d, dy.device)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return dx
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in syms:
         assert hasattr(lib, name), name
     assert sorted(_C.SIGNATURES) == syms  # the Python binding types exactly the declared surface
-    assert _C.load().lvae_abi_version() == 1
+    assert _C.load().lvae_abi_version() == 2
     assert _C.load().lvae_last_error() is not None
 
 

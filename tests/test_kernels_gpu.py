@@ -1,4 +1,5 @@
 """Per-kernel parity on the GPU: each C-ABI entry point against a plain PyTorch fp32 CPU op of the same maths."""
+import ctypes
 import math
 
 import pytest
@@ -88,6 +89,44 @@ def test_conv_fwd_dgrad_wgrad(K, case):
     wc = w.detach().cuda().contiguous()
     yd2 = K.conv2d(nhwc(x.detach()), wc, K.ConvGeom(wc, stride=s, pad=p), bias=b.detach().cuda())
     assert rel(nchw(yd2), y.detach()) < 2e-6
+
+
+WINO_CASES = [
+    (200, 64, 16, 16),   # one image per workgroup
+    (49, 64, 32, 32),    # 8-row tiles of a 32-wide image
+    (770, 64, 8, 8),     # four images per workgroup, ragged last group
+    (193, 100, 16, 16),  # two output-channel tiles, the second ragged
+    (260, 32, 24, 8),    # 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv3x3_winograd(K, case):
+    """Large 3x3 stride-1 layers take the Winograd F(2x2,3x3) kernel (forward and dgrad) when given scratch; it must agree
+    with the direct fp32 sum to a few ulp, including the fused BN/activation prologue and dropout/activation epilogue."""
+    N, Co, H, W = case
+    C = 64
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w = torch.randn(Co, C, 3, 3, generator=g) / 24
+    b = torch.randn(Co, generator=g)
+    drop = (torch.rand(N, Co, generator=g) < 0.8).float() / 0.8
+    xin = F.elu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y = F.elu(F.conv2d(xin.double(), w.double(), b.double(), padding=1) * drop.view(N, Co, 1, 1).double()).float()
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
+    assert K._C.load().lvae_conv2d_workspace(ctypes.byref(d)) > 0, "case is meant to exercise the Winograd path"
+    yd = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
+                  out_scale=drop.cuda(), out_act='elu')
+    assert rel(nchw(yd), y) < 4e-6
+    if Co == 64:
+        dy = torch.randn(N, Co, H, W, generator=g)
+        dx_ref = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+        mask = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
+        dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W), out_scale=mask.cuda())
+        assert rel(nchw(dx), dx_ref * mask.view(N, C, 1, 1)) < 4e-6
 
 
 @pytest.mark.parametrize('case', [(3, 64, 64, 4, 4), (2, 16, 8, 8, 8), (40, 64, 64, 8, 8)])
