@@ -289,6 +289,8 @@ void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, i
                        Cout, stap, sk, sn, dw, db);
 }
 
+size_t conv_wgrad_wino_workspace(const lvae_conv_desc* d);
+int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 size_t conv_wgrad_tile_workspace(const lvae_conv_desc* d);
 int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 
@@ -314,6 +316,8 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
+  const size_t wino = conv_wgrad_wino_workspace(d);
+  if (wino) return wino;
   const size_t halo = conv_wgrad_tile_workspace(d);
   if (halo) return halo;
   int ksplit, pps, ncit, ncot;
@@ -330,6 +334,10 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  if (!halo_off && conv_wgrad_wino_workspace(d)) {
+    const int hr = conv_wgrad_wino_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
   if (!halo_off && conv_wgrad_tile_workspace(d)) {
     const int hr = conv_wgrad_tile_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;

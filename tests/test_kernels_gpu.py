@@ -97,6 +97,7 @@ WINO_CASES = [
     (770, 64, 8, 8),     # four images per workgroup, ragged last group
     (193, 100, 16, 16),  # two output-channel tiles, the second ragged
     (260, 32, 24, 8),    # 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
+    (97, 128, 32, 16),   # four 32-channel blocks in the weight-gradient kernel, ranges of unequal length
 ]
 
 
@@ -121,12 +122,25 @@ def test_conv3x3_winograd(K, case):
     yd = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
                   out_scale=drop.cuda(), out_act='elu')
     assert rel(nchw(yd), y) < 4e-6
+    dy = torch.randn(N, Co, H, W, generator=g)
     if Co == 64:
-        dy = torch.randn(N, Co, H, W, generator=g)
         dx_ref = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
         mask = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
         dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W), out_scale=mask.cuda())
         assert rel(nchw(dx), dx_ref * mask.view(N, C, 1, 1)) < 4e-6
+    # weight / bias gradient (Winograd-domain kernel when Cout is a multiple of 32 and W is 8, 16 or 32), fused prologue,
+    # accumulating into a non-zero gradient
+    xin64 = xin.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    F.conv2d(xin64, w64, b64, padding=1).backward(dy.double())
+    dw0 = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    dw = packed_weight(dw0)
+    db0 = torch.randn(Co, generator=g)
+    db = db0.cuda()
+    K.conv2d_wgrad(nhwc(x), nhwc(dy), wp, geom, dw, db, in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu')
+    assert rel(dw.cpu() - dw0, w64.grad.float()) < 5e-6
+    assert rel(db.cpu() - db0, b64.grad.float()) < 5e-6
 
 
 @pytest.mark.parametrize('case', [(3, 64, 64, 4, 4), (2, 16, 8, 8, 8), (40, 64, 64, 8, 8)])
