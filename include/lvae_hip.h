@@ -72,6 +72,8 @@ typedef struct lvae_conv_desc {
   int32_t gather;        /* LVAE_GATHER_* */
   void* workspace;       /* scratch for lvae_conv2d_f32 (transformed weights of the Winograd path) or NULL */
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
+  int32_t workspace_ready; /* non-zero: `workspace` already holds this descriptor's transformed weights (written by
+                              lvae_conv2d_prepare_weights after the last change of w); the launch skips its own transform */
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -79,6 +81,15 @@ typedef struct lvae_conv_desc {
  * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
 size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+
+/* Batched weight pre-transform: one launch for every convolution of a training step instead of one per convolution call.
+ * For each descriptor with lvae_conv2d_workspace(d) > 0 give it a PRIVATE scratch buffer in d->workspace (kept until the
+ * weights change), let lvae_conv2d_prepare_entry write its lvae_conv2d_prepare_entry_bytes()-byte table entry, copy the
+ * table to device memory once, and call lvae_conv2d_prepare_weights(table, n, largest Cout) after every optimizer step;
+ * convolutions then run with d->workspace_ready = 1. */
+size_t lvae_conv2d_prepare_entry_bytes(void);
+int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry);
+int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout, void* stream);
 
 /* GateLayer2d forward fused with its 1x1 convolution and the residual add — lib/nn.py:118-126 and lib/nn.py:99.
  * `d` describes the 1x1 conv C -> 2C (d->y receives the pre-activations ab [N,H,W,2C] when non-NULL: the backward

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
         ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32),
     ]
 
 
@@ -40,6 +40,9 @@ SIGNATURES = {
     'lvae_last_error': (C.c_char_p, []),
     'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv2d_prepare_entry_bytes': (_Z, []),
+    'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv2d_prepare_weights': (C.c_int, [_P, _I, _I, _P]),
     'lvae_conv1x1_gate_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),

@@ -152,13 +152,31 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(WgWinoArgs a) {
     const float* pa = buf + xoff_a;
     const float* pb = buf + xoff_b;
     const float* pd = buf + doff;
-#pragma unroll
-    for (int ss = 0; ss < 4; ++ss) {
+    // LDS reads of k-step ss+1 are issued before the MFMAs of k-step ss (their latency hides under 512 MFMA cycles)
+    float rxa[4], rxb[4], ry[2][4];
+    auto read_step = [&](int ss) {
       const int cx = TPR == 4 ? 2 * (ss >> 1) * HW2 + 4 * (ss & 1) : 4 * ss;  // pixels
       const int cd = TPR == 4 ? 2 * (ss >> 1) * W + 4 * (ss & 1) : 4 * ss;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        rxa[cc] = pa[(cx + cc) * WG_XS];
+        rxb[cc] = pb[(cx + cc) * WG_XS];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* q = pd + cd * WG_DS + 32 * h;
+        ry[h][0] = q[0];
+        ry[h][1] = q[WG_DS];
+        ry[h][2] = q[W * WG_DS];
+        ry[h][3] = q[(W + 1) * WG_DS];
+      }
+    };
+    read_step(0);
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
       float tt[4], vv[4];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) tt[cc] = __builtin_fmaf(sgn, pb[(cx + cc) * WG_XS], pa[(cx + cc) * WG_XS]);
+      for (int cc = 0; cc < 4; ++cc) tt[cc] = __builtin_fmaf(sgn, rxb[cc], rxa[cc]);
       vv[0] = tt[0] - tt[2];
       vv[1] = tt[1] + tt[2];
       vv[2] = tt[2] - tt[1];
@@ -166,19 +184,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(WgWinoArgs a) {
       float ww[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float* q = pd + cd * WG_DS + 32 * h;
-        const float y00 = q[0], y01 = q[WG_DS], y10 = q[W * WG_DS], y11 = q[(W + 1) * WG_DS];
-        const float s0 = __builtin_fmaf(beta, y10, alpha * y00), s1 = __builtin_fmaf(beta, y11, alpha * y01);
+        const float s0 = __builtin_fmaf(beta, ry[h][2], alpha * ry[h][0]), s1 = __builtin_fmaf(beta, ry[h][3], alpha * ry[h][1]);
         ww[h][0] = s0;
         ww[h][1] = s0 + s1;
         ww[h][2] = s0 - s1;
         ww[h][3] = -s1;
         dbacc[h] += ww[h][1];  // position (1,1) of A dY A^T is the plain sum of the 2x2 block (used from the pi == 1 waves)
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ss + 1 < 4) read_step(ss + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j], ww[h][j], acc[j][h], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (c + 1 < c_end) {
       store_chunk(smem + ((c + 1 - c_begin) & 1) * BUF);

@@ -20,6 +20,7 @@
 // The inverse transform is separable: each wave reduces its row to R[i][b] = sum_j M[i][j] A[j][b] lane-locally,
 // the four rows meet in LDS, and the store pass forms Y[a][b] = sum_i A[a][i] R[i][b] with bias/dropout/activation.
 #include <stdlib.h>
+#include <string.h>
 
 #include "lvae_common.h"
 
@@ -61,6 +62,49 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     float* dst = U + (size_t)(a * 4) * slab + idx;
+    dst[0] = t[a][0];
+    dst[slab] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    dst[2 * slab] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+    dst[3 * slab] = t[a][2];
+  }
+}
+
+// ---- the same transform for many weight tensors in one launch (blockIdx.y = entry): lvae_conv2d_prepare_weights
+struct WinoPrepEntry {
+  const float* w;
+  float* U;
+  int64_t stap, sk, sn;
+  int32_t K, N, Npad, flip;
+  int64_t pad_;
+};
+static_assert(sizeof(WinoPrepEntry) == 64, "entry layout is part of the C ABI (lvae_conv2d_prepare_entry)");
+
+__global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrepEntry* __restrict__ entries) {
+  const WinoPrepEntry e = entries[blockIdx.y];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= e.Npad * 64) return;
+  const int c = idx & 3, n = (idx >> 2) % e.Npad, kq = (idx >> 2) / e.Npad;
+  const int k = kq * 4 + c;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int tap = e.flip ? (2 - a) * 3 + (2 - b) : a * 3 + b;
+      g[a][b] = (n < e.N && k < e.K) ? e.w[tap * e.stap + (int64_t)k * e.sk + (int64_t)n * e.sn] : 0.f;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+  const size_t slab = (size_t)e.Npad * 64;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float* dst = e.U + (size_t)(a * 4) * slab + idx;
     dst[0] = t[a][0];
     dst[slab] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
     dst[2 * slab] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
@@ -322,9 +366,11 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   float* U = static_cast<float*>(workspace);
   a.U = U;
   const int Npad = a.Npad;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * 64 + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
-                     d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
-  LVAE_LAUNCH_CHECK("wino_weight");
+  if (!d->workspace_ready) {
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * 64 + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
+                       d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
+    LVAE_LAUNCH_CHECK("wino_weight");
+  }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
   switch (a.debug) {
@@ -341,3 +387,36 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
 }
 
 }  // namespace lvae
+
+using namespace lvae;
+
+extern "C" size_t lvae_conv2d_prepare_entry_bytes(void) { return sizeof(WinoPrepEntry); }
+
+extern "C" int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry) {
+  LVAE_REQUIRE(d && entry, LVAE_EINVAL, "lvae_conv2d_prepare_entry: null pointer");
+  LVAE_REQUIRE(conv3x3_wino_eligible(d) && d->workspace && (size_t)d->workspace_bytes >= conv3x3_wino_workspace(d) &&
+                   al16w2(d->workspace),
+               LVAE_EINVAL, "lvae_conv2d_prepare_entry: descriptor has no weight pre-transform (lvae_conv2d_workspace(d) == 0) or no scratch");
+  WinoPrepEntry e;
+  e.w = d->w;
+  e.U = static_cast<float*>(d->workspace);
+  e.stap = d->w_stap;
+  e.sk = d->w_sk;
+  e.sn = d->w_sn;
+  e.K = d->C1;
+  e.N = d->Cout;
+  e.Npad = (d->Cout + 63) / 64 * 64;
+  e.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
+  e.pad_ = 0;
+  memcpy(entry, &e, sizeof(e));
+  return 0;
+}
+
+extern "C" int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout, void* stream) {
+  LVAE_REQUIRE(entries && n > 0 && n < 65536 && max_cout > 0, LVAE_EINVAL, "lvae_conv2d_prepare_weights: bad arguments");
+  const int npad = (max_cout + 63) / 64 * 64;
+  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3((npad * 64 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WinoPrepEntry*>(entries));
+  LVAE_LAUNCH_CHECK("wino_weight_batched");
+  return 0;
+}

@@ -80,3 +80,5 @@ def broadcast_flat(flat, src=0, group=None):
     """Identical initial replicas: broadcast rank `src`'s flat parameter arena once."""
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get('LVAE_FORCE_DIST') == '1'):
         dist.broadcast(flat, src=src, group=group)
+        from . import kernels
+        kernels.prepared.weights_written()  # parameter views do not share the flat buffer's version counter

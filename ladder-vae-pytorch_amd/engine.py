@@ -50,6 +50,7 @@ class TrainStep:
 
     def _fwd_bwd(self, x):
         self.opt.zero_grad()
+        K.prepared.prepare_all()  # one launch: transformed weights of every Winograd convolution seen so far
         out = forward_pass(self.model, x, self.beta)
         ops.set_wgrad_stream(self.side)
         try:
@@ -98,6 +99,7 @@ class TrainStep:
         if self.graph_b is not None:
             self.allreduce.run()
             self.graph_b.replay()
+        K.prepared.weights_written()  # the replayed optimizer kernel changed the weights behind Python's back
         if self.model.training and not just_captured:
             for bn in self._bns:
                 bn._pending += 1

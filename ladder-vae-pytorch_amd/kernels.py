@@ -72,11 +72,78 @@ def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, b
     return d
 
 
-def _conv_ws(d, device):
+class _PreparedWeights:
+    """Transformed-weight cache of the Winograd convolutions (lvae_conv2d_prepare_weights).
+
+    Every eligible (weight view, orientation) gets a private scratch buffer; `prepare_all()` refreshes all of them in ONE
+    launch (the training step calls it right after the optimizer has written the weights) and a convolution whose entry is
+    current runs with workspace_ready = 1. An entry is current while neither the tensor's autograd version counter (any
+    torch in-place op: load_state_dict, copy_, ...) nor `epoch` (bumped by every kernel of this package that writes weights
+    through raw pointers: Adamax, broadcast, graph replays) has moved since it was written; otherwise the convolution falls
+    back to transforming its weights itself, so a stale buffer is never read.
+    """
+
+    def __init__(self):
+        self.entries = {}   # key -> dict(weight, U, desc bytes, stamp)
+        self.epoch = 0
+        self.table = None   # device table of the entries, rebuilt when the set changes
+        self.table_keys = None
+        self.max_cout = 0
+        self.enabled = True
+
+    def stamp(self, weight):
+        return (weight._version, self.epoch)
+
+    def attach(self, d, weight, device, need):
+        key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, device.index)
+        ent = self.entries.get(key)
+        if ent is None:
+            ent = {'weight': weight, 'U': torch.empty(int(need), dtype=torch.uint8, device=device), 'stamp': None, 'entry': None}
+            d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
+            raw = (C.c_char * _C.load().lvae_conv2d_prepare_entry_bytes())()
+            call('lvae_conv2d_prepare_entry', C.byref(d), C.cast(raw, C.c_void_p))
+            ent['entry'] = bytes(raw)
+            ent['cout'] = d.Cout
+            self.entries[key] = ent
+            self.table = None
+        d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
+        d.workspace_ready = 1 if (self.enabled and ent['stamp'] == self.stamp(ent['weight'])) else 0
+
+    def prepare_all(self):
+        """One launch that (re)writes every registered buffer from the current weights. Returns the number of entries."""
+        if not self.entries or not self.enabled:
+            return 0
+        by_dev = {}
+        for k, e in self.entries.items():
+            by_dev.setdefault(k[-1], []).append(e)
+        if self.table is None:
+            if torch.cuda.is_current_stream_capturing():
+                return 0  # the table upload is a host copy: convolutions transform their own weights until an eager step built it
+            self.table = {}
+            for dev, ents in by_dev.items():
+                blob = b''.join(e['entry'] for e in ents)
+                t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(torch.device('cuda', dev))
+                self.table[dev] = (t, len(ents), max(e['cout'] for e in ents))
+        for dev, ents in by_dev.items():
+            t, n, max_cout = self.table[dev]
+            with torch.cuda.device(dev):
+                call('lvae_conv2d_prepare_weights', t.data_ptr(), n, max_cout, stream_ptr())
+            for e in ents:
+                e['stamp'] = self.stamp(e['weight'])
+        return len(self.entries)
+
+    def weights_written(self):
+        """Call after weights were modified through raw pointers (optimizer kernel, collective, graph replay)."""
+        self.epoch += 1
+
+
+prepared = _PreparedWeights()
+
+
+def _conv_ws(d, weight, device):
     need = _C.load().lvae_conv2d_workspace(C.byref(d))
     if need:
-        ws = workspace(need, device)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        prepared.attach(d, weight, device, need)
 
 
 def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None):
@@ -92,7 +159,7 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     y = torch.empty((N, OH, OW, g.Cout), dtype=torch.float32, device=x.device)
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
-    _conv_ws(d, x.device)
+    _conv_ws(d, weight, x.device)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return y
 
@@ -127,7 +194,7 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
     d = _desc(g, weight, dy, None, N, OH, OW, H, W, b - a, g.s_co, g.s_ci,
               GATHER_CONV if g.transposed else GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     d.w = ptr(weight) + 4 * a * g.s_ci
-    _conv_ws(d, dy.device)
+    _conv_ws(d, weight, dy.device)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return dx
 
@@ -398,6 +465,7 @@ def iw_logmeanexp(elbo_sn):
 def adamax_step(p, g, exp_avg, exp_inf, mask, lr, beta1, beta2, eps, weight_decay, gscale, step_count):
     call('lvae_adamax_step_f32', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_inf), ptr(mask), p.numel(), lr, beta1, beta2, eps,
          weight_decay, ptr(gscale), step_count.data_ptr(), stream_ptr())
+    prepared.weights_written()
 
 
 def l2norm(x, out=None):

@@ -143,6 +143,40 @@ def test_conv3x3_winograd(K, case):
     assert rel(db.cpu() - db0, b64.grad.float()) < 5e-6
 
 
+def test_prepared_weights_cache(K):
+    """lvae_conv2d_prepare_weights: one batched transform serves later convolutions; any write to the weights (torch in-place
+    op or a raw-pointer kernel announced through weights_written) makes the convolution transform them itself again."""
+    g = torch.Generator().manual_seed(21)
+    N, C, H, W = 200, 64, 16, 16
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / 24
+    dy = torch.randn(N, C, H, W, generator=g)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    xd, dyd = nhwc(x), nhwc(dy)
+    K.prepared.entries.clear()
+    K.prepared.table = None
+    y0, dx0 = K.conv2d(xd, wp, geom), K.conv2d_dgrad(dyd, wp, geom, (H, W))      # registers both orientations
+    assert len(K.prepared.entries) == 2 and all(e['stamp'] is None for e in K.prepared.entries.values())
+    assert K.prepared.prepare_all() == 2
+    for e in K.prepared.entries.values():
+        assert e['stamp'] == K.prepared.stamp(wp)
+        e['U'].zero_()                                                           # a launch that re-transformed would not care
+    K.prepared.prepare_all()
+    y1, dx1 = K.conv2d(xd, wp, geom), K.conv2d_dgrad(dyd, wp, geom, (H, W))      # served from the prepared buffers
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    wp.mul_(2.0)                                                                  # torch in-place write: version counter moves
+    y2 = K.conv2d(xd, wp, geom)
+    assert rel(y2, 2 * y0) < 1e-6
+    K.prepared.prepare_all()
+    K.prepared.weights_written()                                                  # e.g. the Adamax kernel ran
+    for e in K.prepared.entries.values():
+        e['U'].zero_()                                                           # stale garbage must not be read
+    assert rel(K.conv2d(xd, wp, geom), 2 * y0) < 1e-6
+    K.prepared.entries.clear()
+    K.prepared.table = None
+
+
 @pytest.mark.parametrize('case', [(3, 64, 64, 4, 4), (2, 16, 8, 8, 8), (40, 64, 64, 8, 8)])
 def test_conv_transpose(K, case):
     N, Ci, Co, H, W = case
