@@ -35,9 +35,11 @@ def forward_pass(model, x, beta=1.0, compute_l2=True):
 class TrainStep:
     """step(x) -> dict of scalars (device tensors, valid until the next step)."""
 
-    def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2, async_wgrad=True):
+    def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2, async_wgrad=False,
+                 wgrad_streams=1):
         self.model, self.opt, self.beta = model, optimizer, beta
-        self.side = torch.cuda.Stream(device=next(model.parameters()).device) if async_wgrad else None
+        dev = next(model.parameters()).device
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(wgrad_streams)))] if async_wgrad else None
         self.use_graph, self.allreduce = use_graph, allreduce
         self.eager_left = eager_warmup if use_graph else -1
         self.graph_a = self.graph_b = None
@@ -55,7 +57,8 @@ class TrainStep:
         ops.set_wgrad_stream(self.side)
         try:
             if self.side is not None:
-                self.side.wait_stream(torch.cuda.current_stream())  # zero_grad happens-before every wgrad accumulate
+                for st in self.side:
+                    st.wait_stream(torch.cuda.current_stream())  # zero_grad happens-before every wgrad accumulate
             out['loss'].backward()
             ops.join_wgrad_stream()
         finally:

@@ -42,20 +42,27 @@ def _c(t):
 _side = {'stream': None}
 
 
-def set_wgrad_stream(stream):
-    _side['stream'] = stream
+def set_wgrad_stream(streams):
+    """None, one stream, or a list of streams the weight-gradient kernels are spread over (they depend on nothing but
+    their inputs, and the small layers' launches fill only a fraction of the CUs each)."""
+    if streams is None:
+        _side['stream'] = None
+    else:
+        _side['stream'] = list(streams) if isinstance(streams, (list, tuple)) else [streams]
 
 
 def join_wgrad_stream():
-    st = _side['stream']
-    if st is not None:
-        torch.cuda.current_stream().wait_stream(st)
+    sts = _side['stream']
+    if sts is not None:
+        for st in sts:
+            torch.cuda.current_stream().wait_stream(st)
 
 
 def wgrad(x, dy, w, g, dw, db, **kw):
-    st = _side['stream']
-    if st is None:
+    sts = _side['stream']
+    if sts is None:
         return K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)
+    st = sts[(dw.data_ptr() >> 8) % len(sts)]  # one weight always on the same stream: its accumulations stay ordered
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)
