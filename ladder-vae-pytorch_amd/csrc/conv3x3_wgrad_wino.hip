@@ -308,14 +308,16 @@ static bool wg_wino_plan(const lvae_conv_desc* d, WgWinoArgs& a) {
   if ((d->H / 2) % tr != 0) return false;
   if (!al16g(d->x) || !al16g(d->in_scale) || !al16g(d->in_shift)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  static const int64_t min_m = getenv("LVAE_WINO_WGRAD_MIN_M") ? atoll(getenv("LVAE_WINO_WGRAD_MIN_M")) : 256 * 192;  // tuning switch
+  static const int64_t min_m = getenv("LVAE_WINO_WGRAD_MIN_M") ? atoll(getenv("LVAE_WINO_WGRAD_MIN_M")) : 256 * 64;  // tuning switch
   if (M < min_m || M * 256 >= ((int64_t)1 << 31)) return false;
   a.ncog = d->Cout / 64;
   a.cpi = (d->H / 2) / tr;
   a.total_chunks = d->N * a.cpi;
   int nranges = 128 / a.ncog;  // 256 workgroups with the two input-channel blocks
   if (nranges < 1) nranges = 1;
-  if (nranges > a.total_chunks) nranges = a.total_chunks;
+  static const int min_cpr = getenv("LVAE_WINO_WGRAD_MIN_CPR") ? atoi(getenv("LVAE_WINO_WGRAD_MIN_CPR")) : 4;  // tuning switch
+  if (nranges > a.total_chunks / min_cpr) nranges = a.total_chunks / min_cpr;  // slab traffic: at least min_cpr chunks per slab
+  if (nranges < 1) nranges = 1;
   a.cpr = (a.total_chunks + nranges - 1) / nranges;
   a.nranges = (a.total_chunks + a.cpr - 1) / a.cpr;
   a.m_cpi = fastdiv_magic(a.cpi);
