@@ -6,8 +6,10 @@ default init under torch.manual_seed(42). Inputs are resident in HBM before the 
 rank processes its own 256-image shard; `value` = images of all ranks / max-over-ranks time.
 
 Extra objects in the JSON line:
-  roofline     — fp32-MFMA roofline of the dominant kernel family (conv_igemm_kernel, forward + dgrad launches), from an
-                 instrumented eager step timed with HIP events on the launch stream (not part of `value`);
+  roofline     — fp32-MFMA roofline of the dominant kernel (the forward + dgrad launches of the most expensive convolution
+                 shape), from an instrumented eager step timed with HIP events on the launch stream (not part of `value`);
+                 `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs, `mfma_util` the MFMA FLOPs the kernel really
+                 issues (Winograd F(2x2,3x3) issues 16/36 of them);
   cpu_baseline — the CPU oracle (oracle/lvae_ref.py, a port of the reference) timed on this box's host cores on a
                  bounded sample (rank 0, N=1 only).
 """
@@ -55,6 +57,7 @@ def conv_roofline(model, x):
     from lvae_amd import kernels as K
     from lvae_amd.engine import forward_pass
     rec = []
+    wino = set()
     orig = K.call
 
     def timed_call(name, *args):
@@ -66,6 +69,8 @@ def conv_roofline(model, x):
             flops /= d.stride * d.stride  # taps that hit no input pixel are not algorithmic work
         nbytes = 4.0 * (d.N * d.H * d.W * (d.C1 + d.C2) + d.N * d.OH * d.OW * d.Cout + d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
         key = 'conv %dx%d s%d %d->%d @%dx%dx%d' % (d.KH, d.KW, d.stride, d.C1 + d.C2, d.Cout, d.N, d.OH, d.OW)
+        if name == 'lvae_conv2d_f32' and K._C.load().lvae_conv2d_workspace(args[0]) > 0:
+            wino.add(key)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig(name, *args)
@@ -75,6 +80,7 @@ def conv_roofline(model, x):
     K.call = timed_call
     try:
         model.zero_grad()
+        K.prepared.prepare_all()  # as in the training step: the per-launch records below are the convolution kernels alone
         out = forward_pass(model, x)
         out['loss'].backward()
         torch.cuda.synchronize()
@@ -90,17 +96,18 @@ def conv_roofline(model, x):
     dom = max(groups.items(), key=lambda kv: kv[1][3])
     fam_f = sum(g[1] for g in groups.values())
     fam_ms = sum(g[3] for g in groups.values())
-    return dom, fam_f, fam_ms, len(rec)
+    return dom, fam_f, fam_ms, len(rec), dom[0] in wino
 
 
-def pmc_traffic(dom_key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/r01_pmc/hbm_traffic.json);
-    only the shape that was actually profiled (3x3 64->64 @256x16x16, conv3x3_halo_kernel<128,64,*> on 512 workgroups)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc', 'hbm_traffic.json')
+def pmc_traffic(dom_key, is_wino):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (profiles/r01_pmc2/hbm_traffic.json);
+    only the shape that was actually profiled (3x3 64->64 @256x16x16 on 512 workgroups)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc2', 'hbm_traffic.json')
     if dom_key != 'conv 3x3 s1 64->64 @256x16x16' or not os.path.exists(path):
         return None
     ks = json.load(open(path))['kernels']
-    vals = [v['hbm_bytes_per_launch'] for k, v in ks.items() if k.startswith('conv3x3_halo_kernel<128, 64') and k.endswith('@512 workgroups')]
+    prefix = 'conv3x3_wino_kernel' if is_wino else 'conv3x3_halo_kernel'
+    vals = [v['hbm_bytes_per_launch'] for k, v in ks.items() if k.startswith(prefix) and k.endswith('@512 workgroups')]
     return sum(vals) / len(vals) if vals else None
 
 
@@ -216,12 +223,15 @@ def main():
             'neg_elbo': -elbo, 'loss': loss,
         }
     if rank == 0 and not args.no_roofline:
-        (dkey, (dn, dflops, dbytes, dms)), fam_f, fam_ms, n = conv_roofline(model, ring[0])
+        (dkey, (dn, dflops, dbytes, dms)), fam_f, fam_ms, n, is_wino = conv_roofline(model, ring[0])
         ach = dflops / (dms * 1e-3) / 1e12
+        issued = 16.0 / 36.0 if is_wino else 1.0
         line['roofline'] = {
             'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32,
-            'traffic': pmc_traffic(dkey),
-            'kernel': 'conv3x3_halo_kernel (forward + dgrad launches of: %s)' % dkey,
+            'traffic': pmc_traffic(dkey, is_wino),
+            'kernel': '%s (forward + dgrad launches of: %s)' % ('conv3x3_wino_kernel' if is_wino else 'conv3x3_halo_kernel', dkey),
+            'flops_counted': 'algorithmic: direct convolution, 2*N*OH*OW*Cout*Cin*KH*KW per launch',
+            'mfma_flops_issued_fraction': issued, 'mfma_util': ach * issued / PEAK_MFMA_F32,
             'launches_per_step': dn, 'avg_launch_us': dms * 1e3 / dn, 'flops_per_launch': dflops / dn,
             'algorithmic_bytes_per_launch': dbytes / dn,
             'all_conv_fwd_dgrad': {'launches_per_step': n, 'flops_per_step': fam_f, 'ms_per_step': fam_ms,
