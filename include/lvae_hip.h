@@ -107,6 +107,14 @@ int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act
 size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* n independent weight gradients (descs[i], dy[i], dw[i], db[i]; db[i] may be NULL): same results as n calls of
+ * lvae_conv2d_wgrad_f32 in index order. The low-resolution levels of the ladder fill 16-64 CUs per gradient and depend on
+ * nothing but their own inputs, so launches that share a kernel variant go out together (up to 12 per launch, one grouped
+ * slab reduction); everything else is issued one by one. No two entries may accumulate into overlapping dw/db.
+ * workspace: lvae_conv2d_wgrad_grouped_workspace(descs, n) bytes. */
+size_t lvae_conv2d_wgrad_grouped_workspace(const lvae_conv_desc* descs, int32_t n);
+int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const float* const* dy, float* const* dw, float* const* db,
+                                  int32_t n, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d (training statistics) — lib/nn.py:80-81 (nn.BatchNorm2d, momentum 0.1, eps 1e-5)

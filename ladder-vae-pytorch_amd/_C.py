@@ -46,6 +46,8 @@ SIGNATURES = {
     'lvae_conv1x1_gate_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    'lvae_conv2d_wgrad_grouped_workspace': (_Z, [C.POINTER(ConvDesc), _I]),
+    'lvae_conv2d_wgrad_grouped_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),
     'lvae_bn_stats_f32': (C.c_int, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     'lvae_bn_eval_coeffs_f32': (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -9,6 +9,8 @@
 // fixed order (bitwise reproducible, no float atomics) and accumulates into the gradient arena.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -289,7 +291,73 @@ void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, i
                        Cout, stap, sk, sn, dw, db);
 }
 
+struct ReduceArgs {
+  const float* slab_w;
+  const float* slab_b;
+  int ksplit, ntaps, Cin, Cout;
+  int64_t stap, sk, sn;
+  float* dw;
+  float* db;
+};
+constexpr int kMaxReduceGroup = 12;
+struct ReduceGroup {
+  ReduceArgs p[kMaxReduceGroup];
+};
+
+// blockIdx.y = problem; same element mapping as wgrad_reduce_kernel<4> (all grouped problems are float4-aligned)
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(ReduceGroup g) {
+  __shared__ float red[16][16 * 4];
+  const ReduceArgs& a = g.p[blockIdx.y];
+  const int per = a.ntaps * a.Cin * a.Cout;
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int idx = (blockIdx.x * 16 + e) * 4;
+  if ((int)blockIdx.x * 64 >= per + (a.slab_b ? a.Cout : 0)) return;  // uniform per workgroup
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* src = nullptr;
+  int64_t stride = 0;
+  if (idx < per) {
+    src = a.slab_w + idx;
+    stride = per;
+  } else if (a.db && idx < per + a.Cout) {
+    src = a.slab_b + (idx - per);
+    stride = a.Cout;
+  }
+  if (src)
+    for (int k = q; k < a.ksplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+  *reinterpret_cast<f32x4*>(&red[q][e * 4]) = s;
+  __syncthreads();
+  if (q != 0 || !src) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][e * 4 + j];
+    const int i = idx + j;
+    if (i < per) {
+      const int co = i % a.Cout, r2 = i / a.Cout, ci = r2 % a.Cin, tap = r2 / a.Cin;
+      a.dw[tap * a.stap + ci * a.sk + co * a.sn] += t;
+    } else if (i < per + a.Cout) {
+      a.db[i - per] += t;
+    }
+  }
+}
+
+void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s) {
+  ReduceGroup g;
+  int max_tot = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = r[i];
+    const int tot = r[i].ntaps * r[i].Cin * r[i].Cout + (r[i].db ? r[i].Cout : 0);
+    if (tot > max_tot) max_tot = tot;
+  }
+  for (int i = n; i < kMaxReduceGroup; ++i) g.p[i] = g.p[0];
+  hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3((max_tot / 4 + 15) / 16, n), dim3(256), 0, s, g);
+}
+
 size_t conv_wgrad_wino_workspace(const lvae_conv_desc* d);
+int conv_wgrad_tile_kind(const lvae_conv_desc* d);
+int conv_wgrad_tile_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
+                            void* const* workspace, int n, int kind, hipStream_t s);
 int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 size_t conv_wgrad_tile_workspace(const lvae_conv_desc* d);
 int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
@@ -365,5 +433,69 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_LAUNCH_CHECK("conv2d_wgrad");
   wgrad_reduce_launch(a.slab_w, a.slab_b, a.ksplit, a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
   LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
+  return 0;
+}
+
+// n independent weight gradients; same result as n calls of lvae_conv2d_wgrad_f32. Launches that share a tile-kernel
+// variant and are float4-aligned go out together (<= 12 per launch), everything else one by one.
+extern "C" size_t lvae_conv2d_wgrad_grouped_workspace(const lvae_conv_desc* descs, int32_t n) {
+  size_t tot = 0;
+  for (int i = 0; descs && i < n; ++i) tot += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
+  return tot;
+}
+
+extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const float* const* dy, float* const* dw,
+                                             float* const* db, int32_t n, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  LVAE_REQUIRE(descs && dy && dw && db && n > 0 && n <= 4096 && workspace, LVAE_EINVAL, "lvae_conv2d_wgrad_grouped_f32: bad arguments");
+  LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_grouped_workspace(descs, n), LVAE_EWORKSPACE,
+               "lvae_conv2d_wgrad_grouped_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_grouped_workspace(descs, n));
+  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  std::vector<void*> ws(n);
+  std::vector<int> kind(n);
+  char* wp = static_cast<char*>(workspace);
+  for (int i = 0; i < n; ++i) {
+    int rc = conv_desc_check(&descs[i], "lvae_conv2d_wgrad_grouped_f32");
+    if (rc) return rc;
+    LVAE_REQUIRE(dy[i] && dw[i], LVAE_EINVAL, "lvae_conv2d_wgrad_grouped_f32: null dy/dw at %d", i);
+    ws[i] = wp;
+    wp += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
+    const bool groupable = !halo_off && conv_wgrad_wino_workspace(&descs[i]) == 0 && (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0 &&
+                           descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0;
+    kind[i] = groupable ? conv_wgrad_tile_kind(&descs[i]) : -1;
+  }
+  std::vector<char> done(n, 0);
+  for (int k = 0; k < 5; ++k) {
+    const lvae_conv_desc* gd[12];
+    const float* gy[12];
+    float* gw[12];
+    float* gb[12];
+    void* gs[12];
+    int idx[12];
+    int m = 0;
+    auto flush = [&]() -> int {
+      if (m == 0) return 0;
+      int rc = m == 1 ? -1000 : conv_wgrad_tile_grouped(gd, gy, gw, gb, gs, m, k, (hipStream_t)stream);
+      if (rc == 0)
+        for (int j = 0; j < m; ++j) done[idx[j]] = 1;
+      m = 0;
+      return rc == -1000 ? 0 : rc;
+    };
+    for (int i = 0; i < n; ++i) {
+      if (kind[i] != k) continue;
+      gd[m] = &descs[i]; gy[m] = dy[i]; gw[m] = dw[i]; gb[m] = db[i]; gs[m] = ws[i]; idx[m] = i;
+      if (++m == 12) {
+        int rc = flush();
+        if (rc) return rc;
+      }
+    }
+    int rc = flush();
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    int rc = lvae_conv2d_wgrad_f32(&descs[i], dy[i], dw[i], db[i], ws[i], lvae_conv2d_wgrad_workspace(&descs[i]), stream);
+    if (rc) return rc;
+  }
   return 0;
 }

@@ -36,11 +36,12 @@ class TrainStep:
     """step(x) -> dict of scalars (device tensors, valid until the next step)."""
 
     def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2, async_wgrad=False,
-                 wgrad_streams=1):
+                 wgrad_streams=1, wgrad_group_rows=4096):
         self.model, self.opt, self.beta = model, optimizer, beta
         dev = next(model.parameters()).device
         self.side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(wgrad_streams)))] if async_wgrad else None
         self.use_graph, self.allreduce = use_graph, allreduce
+        self.wgrad_group_rows = wgrad_group_rows
         self.eager_left = eager_warmup if use_graph else -1
         self.graph_a = self.graph_b = None
         self.static_x = None
@@ -55,13 +56,16 @@ class TrainStep:
         K.prepared.prepare_all()  # one launch: transformed weights of every Winograd convolution seen so far
         out = forward_pass(self.model, x, self.beta)
         ops.set_wgrad_stream(self.side)
+        ops.set_wgrad_grouping(self.wgrad_group_rows)
         try:
             if self.side is not None:
                 for st in self.side:
                     st.wait_stream(torch.cuda.current_stream())  # zero_grad happens-before every wgrad accumulate
             out['loss'].backward()
+            ops.flush_wgrad_group()
             ops.join_wgrad_stream()
         finally:
+            ops.set_wgrad_grouping(None)
             ops.set_wgrad_stream(None)
         return {k: out[k].detach() for k in ('loss', 'elbo', 'recons', 'kl', 'l2', 'kl_avg_layerwise')}
 

@@ -216,6 +216,29 @@ def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, 
     call('lvae_conv2d_wgrad_f32', C.byref(d), ptr(dy), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())
 
 
+def conv2d_wgrad_grouped(items):
+    """items: list of (x, dy, weight, g, dweight, dbias, kw) exactly as for conv2d_wgrad (kw: x2 / in_scale / in_shift /
+    in_act). One C call; gradients that share a kernel variant are launched together."""
+    n = len(items)
+    descs = (ConvDesc * n)()
+    dys, dws, dbs = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    for i, (x, dy, weight, g, dweight, dbias, kw) in enumerate(items):
+        _chk_nhwc(x, 'x')
+        _chk_nhwc(dy, 'dy')
+        if tuple(dweight.stride()) != tuple(weight.stride()):
+            raise _C.LvaeHipError("conv2d_wgrad_grouped: gradient strides %s differ from weight strides %s" %
+                                  (tuple(dweight.stride()), tuple(weight.stride())))
+        N, H, W, _ = x.shape
+        d = _desc(g, weight, x, kw.get('x2'), N, H, W, dy.shape[1], dy.shape[2], g.Cout, g.s_ci, g.s_co,
+                  GATHER_TRANSPOSED if g.transposed else GATHER_CONV, None, kw.get('in_scale'), kw.get('in_shift'), kw.get('in_act'))
+        C.memmove(C.byref(descs, i * C.sizeof(ConvDesc)), C.byref(d), C.sizeof(ConvDesc))
+        dys[i], dws[i], dbs[i] = ptr(dy), ptr(dweight), ptr(dbias)
+    need = _C.load().lvae_conv2d_wgrad_grouped_workspace(descs, n)
+    ws = workspace(need, items[0][0].device)
+    call('lvae_conv2d_wgrad_grouped_f32', descs, C.cast(dys, C.c_void_p), C.cast(dws, C.c_void_p), C.cast(dbs, C.c_void_p), n,
+         ws.data_ptr(), ws.numel(), stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------------------------
 def bn_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
     """Training-mode BatchNorm statistics of NHWC x. Returns (scale, shift, mean, rstd), each (C,)."""

@@ -58,7 +58,35 @@ def join_wgrad_stream():
             torch.cuda.current_stream().wait_stream(st)
 
 
+def set_wgrad_grouping(max_rows, flush_at=12):
+    """Queue the weight gradients of layers with at most `max_rows` pixels (N*H*W) and issue them `flush_at` at a time through
+    lvae_conv2d_wgrad_grouped_f32 (None switches grouping off and flushes). The caller must call flush_wgrad_group() before
+    anything reads the gradients."""
+    flush_wgrad_group()
+    _side['group_rows'] = max_rows
+    _side['group_at'] = flush_at
+
+
+def flush_wgrad_group():
+    q, _side['group_q'] = _side.get('group_q') or [], []
+    if len(q) == 1:
+        x, dy, w, g, dw, db, kw = q[0]
+        K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)
+    elif q:
+        K.conv2d_wgrad_grouped(q)
+
+
 def wgrad(x, dy, w, g, dw, db, **kw):
+    rows = _side.get('group_rows')
+    if rows is not None and x.shape[0] * x.shape[1] * x.shape[2] <= rows:
+        q = _side.setdefault('group_q', [])
+        if any(e[4].data_ptr() == dw.data_ptr() for e in q):
+            flush_wgrad_group()  # two gradients of one weight must not share a launch
+            q = _side['group_q']
+        q.append((x, dy, w, g, dw, db, kw))
+        if len(q) >= _side.get('group_at', 12):
+            flush_wgrad_group()
+        return
     sts = _side['stream']
     if sts is None:
         return K.conv2d_wgrad(x, dy, w, g, dw, db, **kw)

@@ -143,6 +143,31 @@ def test_conv3x3_winograd(K, case):
     assert rel(db.cpu() - db0, b64.grad.float()) < 5e-6
 
 
+def test_conv_wgrad_grouped(K):
+    """lvae_conv2d_wgrad_grouped_f32 == the same gradients one by one (mixed 3x3 / 1x1 / large / odd shapes in one call)."""
+    g = torch.Generator().manual_seed(33)
+    specs = [(37, 64, 64, 4, 4, 3, 1), (50, 64, 64, 2, 2, 3, 1), (16, 64, 64, 4, 4, 3, 1), (20, 64, 128, 4, 4, 1, 0), (9, 128, 64, 2, 2, 1, 0),
+             (8, 32, 64, 4, 4, 3, 1), (3, 3, 16, 8, 8, 5, 2), (12, 64, 64, 8, 8, 3, 1)] + [(30 + i, 64, 64, 2, 2, 3, 1) for i in range(14)]
+    items, refs = [], []
+    for (N, Ci, Co, H, W, k, p) in specs:
+        x = torch.randn(N, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+        sc, sh = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+        dy = torch.randn(N, Co, H, W, generator=g)
+        wp = packed_weight(w)
+        geom = K.ConvGeom(wp, 1, p)
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu') if Ci % 4 == 0 else {}
+        dw0 = torch.randn(Co, Ci, k, k, generator=g) * 0.1
+        db0 = torch.randn(Co, generator=g)
+        one_w, one_b = packed_weight(dw0), db0.cuda()
+        K.conv2d_wgrad(nhwc(x), nhwc(dy), wp, geom, one_w, one_b, **kw)
+        refs.append((one_w, one_b))
+        items.append((nhwc(x), nhwc(dy), wp, geom, packed_weight(dw0), db0.cuda(), kw))
+    K.conv2d_wgrad_grouped(items)
+    for (x, dy, wp, geom, dw, db, kw), (rw, rb) in zip(items, refs):
+        assert torch.equal(dw, rw) and torch.equal(db, rb)   # same kernels, same summation order: bitwise equal
+
+
 def test_prepared_weights_cache(K):
     """lvae_conv2d_prepare_weights: one batched transform serves later convolutions; any write to the weights (torch in-place
     op or a raw-pointer kernel announced through weights_written) makes the convolution transform them itself again."""
