@@ -36,7 +36,7 @@ class TrainStep:
     """step(x) -> dict of scalars (device tensors, valid until the next step)."""
 
     def __init__(self, model, optimizer, beta=1.0, use_graph=True, allreduce=None, eager_warmup=2, async_wgrad=False,
-                 wgrad_streams=1, wgrad_group_rows=4096):
+                 wgrad_streams=1, wgrad_group_rows=16384):
         self.model, self.opt, self.beta = model, optimizer, beta
         dev = next(model.parameters()).device
         self.side = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(wgrad_streams)))] if async_wgrad else None
