@@ -355,6 +355,8 @@ void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s) {
 }
 
 size_t conv_wgrad_wino_workspace(const lvae_conv_desc* d);
+int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
+                            void* const* workspace, int n, hipStream_t s);
 int conv_wgrad_tile_kind(const lvae_conv_desc* d);
 int conv_wgrad_tile_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
                             void* const* workspace, int n, int kind, hipStream_t s);
@@ -460,12 +462,15 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     LVAE_REQUIRE(dy[i] && dw[i], LVAE_EINVAL, "lvae_conv2d_wgrad_grouped_f32: null dy/dw at %d", i);
     ws[i] = wp;
     wp += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
-    const bool groupable = !halo_off && conv_wgrad_wino_workspace(&descs[i]) == 0 && (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0 &&
-                           descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0;
-    kind[i] = groupable ? conv_wgrad_tile_kind(&descs[i]) : -1;
+    const bool al = (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
+    const bool wino = !halo_off && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
+    const bool groupable = !halo_off && !wino && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0;
+    // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
+    kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < 65536 ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
+                   : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1);
   }
   std::vector<char> done(n, 0);
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 8; ++k) {
     const lvae_conv_desc* gd[12];
     const float* gy[12];
     float* gw[12];
@@ -475,7 +480,9 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     int m = 0;
     auto flush = [&]() -> int {
       if (m == 0) return 0;
-      int rc = m == 1 ? -1000 : conv_wgrad_tile_grouped(gd, gy, gw, gb, gs, m, k, (hipStream_t)stream);
+      int rc = m == 1 ? -1000
+                      : (k >= 5 ? conv_wgrad_wino_grouped(gd, gy, gw, gb, gs, m, (hipStream_t)stream)
+                                : conv_wgrad_tile_grouped(gd, gy, gw, gb, gs, m, k, (hipStream_t)stream));
       if (rc == 0)
         for (int j = 0; j < m; ++j) done[idx[j]] = 1;
       m = 0;

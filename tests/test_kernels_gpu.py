@@ -147,7 +147,8 @@ def test_conv_wgrad_grouped(K):
     """lvae_conv2d_wgrad_grouped_f32 == the same gradients one by one (mixed 3x3 / 1x1 / large / odd shapes in one call)."""
     g = torch.Generator().manual_seed(33)
     specs = [(37, 64, 64, 4, 4, 3, 1), (50, 64, 64, 2, 2, 3, 1), (16, 64, 64, 4, 4, 3, 1), (20, 64, 128, 4, 4, 1, 0), (9, 128, 64, 2, 2, 1, 0),
-             (8, 32, 64, 4, 4, 3, 1), (3, 3, 16, 8, 8, 5, 2), (12, 64, 64, 8, 8, 3, 1)] + [(30 + i, 64, 64, 2, 2, 3, 1) for i in range(14)]
+             (8, 32, 64, 4, 4, 3, 1), (3, 3, 16, 8, 8, 5, 2), (12, 64, 64, 8, 8, 3, 1),
+             (260, 64, 64, 8, 8, 3, 1), (300, 64, 64, 8, 8, 3, 1), (257, 64, 128, 8, 8, 3, 1)] + [(30 + i, 64, 64, 2, 2, 3, 1) for i in range(14)]
     items, refs = [], []
     for (N, Ci, Co, H, W, k, p) in specs:
         x = torch.randn(N, Ci, H, W, generator=g)
