@@ -52,8 +52,9 @@ template <>
 __device__ __forceinline__ float& at<1>(float& v, int) { return v; }
 
 // ---------------------------------------------------------------------------------------------------------
-// bn_stats: per chunk (pivot, sum(x-pivot), sum((x-pivot)^2), count) per channel
-// ws layout: [chunks][4][C]
+// bn_stats: per chunk (sum(x-pivot), sum((x-pivot)^2)) per channel with ONE pivot for all chunks (pivot[c] = x[0, c]: any
+// value inside the data range conditions the variance; a shared one turns the finalize into plain sums — no per-chunk
+// Chan-combine divisions in double). ws layout: [chunks][2][C]
 // ---------------------------------------------------------------------------------------------------------
 template <int V>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t M, int C, int cols,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   const int64_t r1 = min(M, r0 + rows_per_chunk);
   typename Vec<V>::T piv, s1, s2;
   for (int j = 0; j < V; ++j) at<V>(piv, j) = at<V>(s1, j) = at<V>(s2, j) = 0.f;
-  if (r0 < M) piv = Vec<V>::load(x + r0 * C + col * V);
+  piv = Vec<V>::load(x + col * V);
   if (active) {
     for (int64_t r = r0 + rg; r < r1; r += rpp) {
       typename Vec<V>::T v = Vec<V>::load(x + r * C + col * V);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
   __syncthreads();
   if (t < cols) {
-    float* out = ws + (size_t)blockIdx.x * 4 * C;
+    float* out = ws + (size_t)blockIdx.x * 2 * C;
     for (int j = 0; j < V; ++j) {
       float a = 0.f, b = 0.f;
       for (int g = 0; g < rpp; ++g) {
@@ -91,24 +92,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         b += red[1][(g * cols + t) * 4 + j];
       }
       const int c = t * V + j;
-      out[c] = at<V>(piv, j);
-      out[C + c] = a;
-      out[2 * C + c] = b;
-      out[3 * C + c] = (float)(r1 > r0 ? (r1 - r0) : 0);
+      out[c] = a;
+      out[C + c] = b;
     }
   }
-}
-
-__device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
-  if (nb <= 0.0) return;
-  if (n <= 0.0) {
-    n = nb; mean = mb; m2 = m2b;
-    return;
-  }
-  const double delta = mb - mean, nt = n + nb;
-  mean += delta * nb / nt;
-  m2 += m2b + delta * delta * n * nb / nt;
-  n = nt;
 }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int o) {
@@ -118,47 +105,41 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 
-// one 256-thread block per channel: thread k combines chunks k, k+256, ... (Chan et al., double), then a fixed
-// xor-shuffle tree inside each wave and a fixed-order combine of the 4 wave results through LDS
+// one 256-thread block per channel: thread k sums chunks k, k+256, ... in double, then a fixed xor-shuffle tree inside each
+// wave and a fixed-order sum of the 4 wave results through LDS
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
-                                                          const float* gamma, const float* beta, float eps, float momentum,
-                                                          float* running_mean, float* running_var, float* scale,
-                                                          float* shift, float* mean_out, float* rstd_out) {
-  __shared__ double part[4][3];
+                                                          const float* __restrict__ x, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var,
+                                                          float* scale, float* shift, float* mean_out, float* rstd_out) {
+  __shared__ double part[4][2];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
+  double a = 0.0, b = 0.0;
   for (int k = tid; k < chunks; k += 256) {
-    const float* p = ws + (size_t)k * 4 * C;
-    const double nb = p[3 * C + c];
-    if (nb <= 0.0) continue;
-    const double s1 = p[C + c], s2 = p[2 * C + c];
-    chan_combine(n, mean, m2, nb, (double)p[c] + s1 / nb, s2 - s1 * s1 / nb);
+    a += ws[(size_t)k * 2 * C + c];
+    b += ws[(size_t)k * 2 * C + C + c];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const double nb = shfl_xor_d(n, o), mb = shfl_xor_d(mean, o), m2b = shfl_xor_d(m2, o);
-    // lane-order independent: the lower lane index is always the left operand
-    if ((lane & o) == 0) chan_combine(n, mean, m2, nb, mb, m2b);
-    else {
-      double n2 = nb, me2 = mb, mm2 = m2b;
-      chan_combine(n2, me2, mm2, n, mean, m2);
-      n = n2; mean = me2; m2 = mm2;
-    }
+    a += shfl_xor_d(a, o);
+    b += shfl_xor_d(b, o);
   }
   if (lane == 0) {
-    part[wv][0] = n;
-    part[wv][1] = mean;
-    part[wv][2] = m2;
+    part[wv][0] = a;
+    part[wv][1] = b;
   }
   __syncthreads();
   if (tid != 0) return;
-  for (int w = 1; w < 4; ++w) chan_combine(n, mean, m2, part[w][0], part[w][1], part[w][2]);
-  const double var = m2 / (double)M;
+  a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+  b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+  const double inv_m = 1.0 / (double)M, dm = a * inv_m;  // mean - pivot
+  double m2 = b - a * dm;                                 // sum (x - mean)^2
+  if (m2 < 0.0) m2 = 0.0;
+  const double mean = (double)x[c] + dm, var = m2 * inv_m;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   const float sc = g * rstd;
   scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
+  shift[c] = be - (float)mean * sc;
   mean_out[c] = (float)mean;
   rstd_out[c] = rstd;
   if (running_mean) {
@@ -446,7 +427,7 @@ extern "C" int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const flo
   else
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(used), dim3(256), 0, s, x, M, C, rm.cols, rm.rpp, rpc, ws);
   LVAE_LAUNCH_CHECK("bn_partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, used, C, M, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, ws, used, C, M, x, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, mean, rstd);
   LVAE_LAUNCH_CHECK("bn_finalize");
   return 0;
