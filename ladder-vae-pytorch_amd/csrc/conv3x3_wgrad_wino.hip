@@ -58,8 +58,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_grouped_kernel(WgWinoG
 // dw[tap(a,b)][ci][co] += (G^T (sum_ranges slab) G)[a][b]; one 1024-thread workgroup per (ci, group of 64 co): threads =
 // 16 float4 columns x 16 positions x 4 range slices; each range contributes one contiguous 4 KB block; fixed summation order.
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
-                                                                       int nranges, int ncog, int64_t stap, int64_t sk, int64_t sn,
-                                                                       float* dw, float* db) {
+                                                                       int nranges, int ncog, int Cout, int64_t stap, int64_t sk,
+                                                                       int64_t sn, float* dw, float* db) {
   __shared__ float red[4][16][64];
   __shared__ float red_b[16][64];
   const int ci = blockIdx.x / ncog, cog = blockIdx.x % ncog;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const floa
     red_b[slice][co] = v;
   }
   __syncthreads();
-  if (t < 192) {
+  if (t < 192 && cog * 64 + (t & 63) < Cout) {
     const int co = t & 63, ga = t >> 6;  // output row a of G^T dU G
     float u[4][4];
 #pragma unroll
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const floa
     o[stap] += g1;
     o[2 * stap] += g2;
   }
-  if (do_b && t >= 256 && t < 320) {
+  if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < Cout) {
     const int co = t - 256;
     float v = 0.f;
 #pragma unroll
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const floa
 struct WinoReduceArgs {
   const float* slab_w;
   const float* slab_b;
-  int nranges, ncog;
+  int nranges, ncog, Cout, pad_;
   int64_t stap, sk, sn;
   float* dw;
   float* db;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(Wi
     red_b[slice][co] = v;
   }
   __syncthreads();
-  if (t < 192) {
+  if (t < 192 && cog * 64 + (t & 63) < a.Cout) {
     const int co = t & 63, ga = t >> 6;
     float u[4][4];
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(Wi
     o[a.stap] += g1;
     o[2 * a.stap] += g2;
   }
-  if (do_b && t >= 256 && t < 320) {
+  if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < a.Cout) {
     const int co = t - 256;
     float v = 0.f;
 #pragma unroll
@@ -173,7 +173,7 @@ static bool wg_wino_plan(const lvae_conv_desc* d, WgWinoArgs& a) {
   static const bool off = getenv("LVAE_DISABLE_WINO_WGRAD") != nullptr || getenv("LVAE_DISABLE_WINO") != nullptr;  // A/B switch
   if (off) return false;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->gather != LVAE_GATHER_CONV) return false;
-  if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->Cout % 64 != 0 || d->Cout > 256) return false;
+  if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->Cout % 4 != 0 || d->Cout > 256) return false;
   if (d->OH != d->H || d->OW != d->W || (d->H & 1)) return false;
   if (d->W != 8 && d->W != 16 && d->W != 32) return false;
   const int tpr = d->W / 2, tr = 16 / tpr;
@@ -182,7 +182,7 @@ static bool wg_wino_plan(const lvae_conv_desc* d, WgWinoArgs& a) {
   const int64_t M = (int64_t)d->N * d->H * d->W;
   static const int64_t min_m = getenv("LVAE_WINO_WGRAD_MIN_M") ? atoll(getenv("LVAE_WINO_WGRAD_MIN_M")) : 256 * 64;  // tuning switch
   if (M < min_m || M * 256 >= ((int64_t)1 << 31)) return false;
-  a.ncog = d->Cout / 64;
+  a.ncog = (d->Cout + 63) / 64;
   a.cpi = (d->H / 2) / tr;
   a.total_chunks = d->N * a.cpi;
   int nranges = 128 / a.ncog;  // 256 workgroups with the two input-channel blocks
@@ -237,7 +237,7 @@ int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, flo
   else rc = launch_wg_wino<16>(a, s);
   if (rc) return rc;
   hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(64 * a.ncog), dim3(1024), 0, s, a.slab_w, a.slab_b, a.nranges,
-                     a.ncog, d->w_stap, d->w_sk, d->w_sn, dw, db);
+                     a.ncog, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
   LVAE_LAUNCH_CHECK("conv_wgrad_wino_reduce");
   return 0;
 }
@@ -258,7 +258,7 @@ int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const*
     a.slab_b = db[i] ? a.slab_w + (size_t)a.nranges * a.ncog * 2 * 16 * 32 * 64 : nullptr;
     if (a.nranges * a.ncog * 2 > max_wgs) max_wgs = a.nranges * a.ncog * 2;
     if (a.ncog > max_ncog) max_ncog = a.ncog;
-    rg.p[i] = WinoReduceArgs{a.slab_w, a.slab_b, a.nranges, a.ncog, ds[i]->w_stap, ds[i]->w_sk, ds[i]->w_sn, dw[i], db[i]};
+    rg.p[i] = WinoReduceArgs{a.slab_w, a.slab_b, a.nranges, a.ncog, ds[i]->Cout, 0, ds[i]->w_stap, ds[i]->w_sk, ds[i]->w_sn, dw[i], db[i]};
   }
   for (int i = n; i < kMaxWinoGroup; ++i) {
     g.p[i] = g.p[0];
