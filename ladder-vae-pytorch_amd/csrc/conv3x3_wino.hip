@@ -5,7 +5,7 @@
 // (ci, co) pair: 2.25x less MFMA work, same fp32 data, transforms are exact +/- combinations (F(2,3) has only
 // 0, +-1, +-1/2 coefficients, so the extra rounding is a few ulp).
 //
-//   U[p] = G g G^T        (16 position matrices [Cout][Cin], made by wino_weight_kernel once per launch)
+//   U[p] = G g G^T        (16 position matrices [Cout][Cin], made by wino_weight_kernel / wino_weight_batched_kernel)
 //   V[p] = B^T d B        (input transform, in registers, straight from the LDS-resident halo patch)
 //   M[p] = V[p] * U[p]    (16 independent GEMMs over Cin on v_mfma_f32_32x32x2_f32)
 //   Y    = A^T M A        (inverse transform: lane-local, because accumulator register r of every position holds the same
@@ -29,15 +29,15 @@ namespace lvae {
 struct WinoArgs {
   lvae_conv_desc d;
   const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3
-  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, debug;
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, Cin;
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
 };
 
 // ---- weight transform: U[p] = (G g G^T)[p] with g[kh][kw] = w[tap(kh,kw)][k][n] (taps flipped for dgrad)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int64_t stap, int64_t sk, int64_t sn,
-                                                           int K, int N, int Npad, int flip, float* __restrict__ U) {
+                                                           int K, int Kpad, int N, int Npad, int flip, float* __restrict__ U) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Npad * 64) return;
+  if (idx >= Npad * Kpad) return;
   // consecutive threads -> consecutive floats of one position slab [8][2][Npad][4]
   const int e = idx & 3, n = (idx >> 2) % Npad, kq = (idx >> 2) / Npad;  // kq = k / 4
   const int k = kq * 4 + e;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
-  const size_t slab = (size_t)Npad * 64;
+  const size_t slab = (size_t)Npad * Kpad;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     float* dst = U + (size_t)(a * 4) * slab + idx;
@@ -75,14 +75,14 @@ struct WinoPrepEntry {
   float* U;
   int64_t stap, sk, sn;
   int32_t K, N, Npad, flip;
-  int64_t pad_;
+  int32_t Kpad, pad_;
 };
 static_assert(sizeof(WinoPrepEntry) == 64, "entry layout is part of the C ABI (lvae_conv2d_prepare_entry)");
 
 __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrepEntry* __restrict__ entries) {
   const WinoPrepEntry e = entries[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= e.Npad * 64) return;
+  if (idx >= e.Npad * e.Kpad) return;
   const int c = idx & 3, n = (idx >> 2) % e.Npad, kq = (idx >> 2) / e.Npad;
   const int k = kq * 4 + c;
   float g[3][3];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
-  const size_t slab = (size_t)e.Npad * 64;
+  const size_t slab = (size_t)e.Npad * e.Kpad;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     float* dst = e.U + (size_t)(a * 4) * slab + idx;
@@ -112,11 +112,12 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
   }
 }
 
-constexpr int WLDA = 68;  // halo pixel stride (floats)
 constexpr int WLDO = 68;  // R row stride (floats)
 
-template <int DBG>
+template <int CIN>  // reduction channels padded to 64 or 128 (the DMoL head's dgrad reduces over 100)
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+  constexpr int WLDA = CIN + 4;     // halo pixel stride (floats)
+  constexpr int KSTEPS = CIN / 8, NSLICE = CIN / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;  // [halo_px][WLDA]; reused as R[4][2][32][WLDO] by the epilogue
   const lvae_conv_desc& d = a.d;
@@ -146,20 +147,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
     const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
     const bool ok = (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W);
-    hoff[u] = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * 64 + hc4) : ~0u;
+    hoff[u] = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * a.Cin + hc4) : ~0u;
     hlds[u] = px < a.halo_px ? px * WLDA + hc4 : -1;
   }
   f32x4 hreg[SLOTS];
+  unsigned hlive = 0;
   auto load_slice = [&](int c) {
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
-      const unsigned off = hoff[u] == ~0u ? 0u : hoff[u] + 16 * c;
+      const bool live = hoff[u] != ~0u && 16 * c + hc4 < a.Cin;  // channels beyond Cin (CIN padding) read as zero
+      const unsigned off = live ? hoff[u] + 16 * c : 0u;
       hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      hlive = live ? hlive | (1u << u) : hlive & ~(1u << u);
     }
   };
   auto store_slice = [&](int c) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
-    if (d.in_scale) {
+    if (d.in_scale && 16 * c + hc4 < a.Cin) {
       sc = *reinterpret_cast<const f32x4*>(d.in_scale + 16 * c + hc4);
       sh = *reinterpret_cast<const f32x4*>(d.in_shift + 16 * c + hc4);
     }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int u = 0; u < SLOTS; ++u) {
       if (hlds[u] >= 0) {
         f32x4 w = zero4;
-        if (hoff[u] != ~0u) {
+        if ((hlive >> u) & 1u) {
           w = hreg[u];
           if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
         }
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const float* pb = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 4 * lh;
 
   // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
-  const size_t slab = (size_t)a.Npad * 64;
+  const size_t slab = (size_t)a.Npad * CIN;
   const float* ub = a.U + (size_t)(4 * wave) * slab + ((size_t)lh * a.Npad + co0 + li) * 4;
   const size_t kstep = (size_t)2 * a.Npad * 4;
   f32x4 bf[2][4][2];
@@ -215,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   load_slice(1);
   __syncthreads();
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    if (ks + 1 < 8 && !(DBG & 1)) load_u(ks + 1, (ks + 1) & 1);
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    if (ks + 1 < KSTEPS) load_u(ks + 1, (ks + 1) & 1);
     f32x4 tt[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -237,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks & 1][j][h][e], acc[j][h], 0, 0, 0);
-    if ((ks & 1) && ks < 7 && !(DBG & 4)) {  // publish the next 16-channel slice, start fetching the one after
+    if ((ks & 1) && ks < KSTEPS - 1) {  // publish the next 16-channel slice, start fetching the one after
       const int c = (ks + 1) >> 1;
       store_slice(c);
-      if (c + 1 < 4) load_slice(c + 1);
+      if (c + 1 < NSLICE) load_slice(c + 1);
       __syncthreads();
     }
   }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int p = (t >> 4) + 16 * q;
-        if (p < nvalid && !(DBG & 8)) {
+        if (p < nvalid) {
           const int img = fastdiv(p, a.m_thw), pr = p - img * thw;
           const int oy = fastdiv(pr, a.m_tw), ox = pr - oy * a.TW;
           const int tile = img * a.wt_per_img + (oy >> 1) * a.tiles_x + (ox >> 1);
@@ -293,9 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
 static bool al16w2(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static int wino_kpad(const lvae_conv_desc* d) { return d->C1 <= 64 ? 64 : 128; }
+
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d) {
   const int ntn = (d->Cout + 63) / 64;
-  return (size_t)16 * ntn * 64 * 64 * sizeof(float);  // 16 position slabs [8][2][Npad][4]
+  return (size_t)16 * ntn * 64 * wino_kpad(d) * sizeof(float);  // 16 position slabs [Kpad/8][2][Npad][4]
 }
 
 bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
@@ -303,11 +309,11 @@ bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
   if (off) return false;
   const int Cin = d->C1;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;
-  if (Cin != 64 || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->W > 128) return false;
+  if (Cin < 36 || Cin > 128 || Cin % 4 != 0 || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->W > 128) return false;
   if (!al16w2(d->x) || !al16w2(d->y) || !al16w2(d->bias) || !al16w2(d->in_scale) || !al16w2(d->in_shift) || !al16w2(d->out_scale)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
   static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 192;  // tuning switch
-  if (M < min_m || M * 64 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
+  if (M < min_m || M * 128 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
   return true;
 }
 
@@ -337,8 +343,6 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.tiles_x = d->W / 2;
   a.wt_per_img = (TH / 2) * a.tiles_x;
   a.n_wt = NI * a.wt_per_img;
-  static const int dbg = getenv("LVAE_WINO_DEBUG") ? atoi(getenv("LVAE_WINO_DEBUG")) : 0;  // phase-skip switches, profiling only
-  a.debug = dbg;
   a.ntn = (d->Cout + 63) / 64;
   a.Npad = a.ntn * 64;
   a.m_thw = fastdiv_magic(TH * d->W);
@@ -347,16 +351,16 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.m_halo_w = fastdiv_magic(a.halo_w);
   a.m_tiles_x = fastdiv_magic(a.tiles_x);
   a.m_wt_per_img = fastdiv_magic(a.wt_per_img);
-  size_t lds = (size_t)a.halo_px * WLDA * sizeof(float);
+  const int kpad = wino_kpad(d);
+  a.Cin = Cin;
+  size_t lds = (size_t)a.halo_px * (kpad + 4) * sizeof(float);
   const size_t lds_r = (size_t)4 * 2 * 32 * WLDO * sizeof(float);
   if (lds < lds_r) lds = lds_r;
+  if (lds > 160 * 1024) return -1000;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipSuccess;
-    for (const void* f : {(const void*)conv3x3_wino_kernel<0>, (const void*)conv3x3_wino_kernel<1>, (const void*)conv3x3_wino_kernel<2>,
-                          (const void*)conv3x3_wino_kernel<4>, (const void*)conv3x3_wino_kernel<8>, (const void*)conv3x3_wino_kernel<16>,
-                          (const void*)conv3x3_wino_kernel<15>})
-      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -367,21 +371,14 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.U = U;
   const int Npad = a.Npad;
   if (!d->workspace_ready) {
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * 64 + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
-                       d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * kpad + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
+                       kpad, d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
     LVAE_LAUNCH_CHECK("wino_weight");
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  switch (a.debug) {
-    case 1: hipLaunchKernelGGL(conv3x3_wino_kernel<1>, grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(conv3x3_wino_kernel<2>, grid, dim3(256), lds, s, a); break;
-    case 4: hipLaunchKernelGGL(conv3x3_wino_kernel<4>, grid, dim3(256), lds, s, a); break;
-    case 8: hipLaunchKernelGGL(conv3x3_wino_kernel<8>, grid, dim3(256), lds, s, a); break;
-    case 15: hipLaunchKernelGGL(conv3x3_wino_kernel<15>, grid, dim3(256), lds, s, a); break;
-    case 16: hipLaunchKernelGGL(conv3x3_wino_kernel<16>, grid, dim3(256), lds, s, a); break;
-    default: hipLaunchKernelGGL(conv3x3_wino_kernel<0>, grid, dim3(256), lds, s, a);
-  }
+  if (kpad == 64) hipLaunchKernelGGL(conv3x3_wino_kernel<64>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv3x3_wino_kernel<128>, grid, dim3(256), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wino");
   return 0;
 }
@@ -407,6 +404,7 @@ extern "C" int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry) {
   e.N = d->Cout;
   e.Npad = (d->Cout + 63) / 64 * 64;
   e.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
+  e.Kpad = wino_kpad(d);
   e.pad_ = 0;
   memcpy(entry, &e, sizeof(e));
   return 0;
@@ -415,7 +413,7 @@ extern "C" int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry) {
 extern "C" int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout, void* stream) {
   LVAE_REQUIRE(entries && n > 0 && n < 65536 && max_cout > 0, LVAE_EINVAL, "lvae_conv2d_prepare_weights: bad arguments");
   const int npad = (max_cout + 63) / 64 * 64;
-  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3((npad * 64 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3((npad * 128 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WinoPrepEntry*>(entries));
   LVAE_LAUNCH_CHECK("wino_weight_batched");
   return 0;
