@@ -361,6 +361,82 @@ int conv_wgrad_tile_kind(const lvae_conv_desc* d);
 int conv_wgrad_tile_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
                             void* const* workspace, int n, int kind, hipStream_t s);
 int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the stem convolutions (5x5 stride 2 on the 1- or 3-channel image): the reduction dimension of the
+// implicit GEMM is wide (all pixels) but its M side is only KH*KW*Cin <= 76 rows, far too thin for the MFMA tile kernels
+// (the generic kernel spends 550 us on 0.6 GFLOP). One workgroup per image: the zero-padded image (<= 32 KB) and the
+// image's dy tile sit in LDS; thread = (co, one of 4 k-groups) keeps 19 accumulators in registers and walks the output
+// pixels (LDS broadcast read of x, one dy value per pixel). Partials go to the usual split-K slabs [image][k][co].
+// ---------------------------------------------------------------------------------------------------------
+struct ThinWgradArgs {
+  lvae_conv_desc d;
+  const float* dy;
+  float* slab_w;
+  float* slab_b;
+  int K, PH, PW;  // K = KH*KW*Cin; padded image height / width
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, n = blockIdx.x;
+  const int Cin = d.C1, npx = d.OH * d.OW;
+  float* xs = smem;                                   // [PH][PW][Cin], zero border
+  float* ys = smem + ((a.PH * a.PW * Cin + 3) & ~3);  // [npx][64]
+  for (int i = t; i < a.PH * a.PW * Cin; i += 256) {
+    const int ci = i % Cin, r = i / Cin, pw = r % a.PW, ph = r / a.PW;
+    const int ih = ph - d.pad, iw = pw - d.pad;
+    xs[i] = ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) ? d.x[((size_t)(n * d.H + ih) * d.W + iw) * Cin + ci] : 0.f;
+  }
+  for (int i = t; i < npx * 64; i += 256) {
+    const int co = i & 63, px = i >> 6;
+    ys[i] = co < d.Cout ? a.dy[((size_t)n * npx + px) * d.Cout + co] : 0.f;
+  }
+  __syncthreads();
+  const int co = t & 63, kg = t >> 6;
+  int koff[19];
+#pragma unroll
+  for (int kk = 0; kk < 19; ++kk) {
+    int k = kg * 19 + kk;
+    if (k >= a.K) k = 0;  // surplus slots recompute k = 0; never stored
+    const int ci = k % Cin, tap = k / Cin, kw = tap % d.KW, kh = tap / d.KW;
+    koff[kk] = (kh * a.PW + kw) * Cin + ci;
+  }
+  float acc[19];
+#pragma unroll
+  for (int kk = 0; kk < 19; ++kk) acc[kk] = 0.f;
+  float bsum = 0.f;
+  for (int oh = 0; oh < d.OH; ++oh) {
+    for (int ow = 0; ow < d.OW; ++ow) {
+      const float g = ys[(oh * d.OW + ow) * 64 + co];
+      const float* xb = xs + ((oh * d.stride) * a.PW + ow * d.stride) * Cin;
+      bsum += g;
+#pragma unroll
+      for (int kk = 0; kk < 19; ++kk) acc[kk] += xb[koff[kk]] * g;
+    }
+  }
+  if (co < d.Cout) {
+    float* slab = a.slab_w + (size_t)n * a.K * d.Cout;
+#pragma unroll
+    for (int kk = 0; kk < 19; ++kk) {
+      const int k = kg * 19 + kk;
+      if (k < a.K) slab[(size_t)k * d.Cout + co] = acc[kk];
+    }
+    if (a.slab_b && kg == 0) a.slab_b[(size_t)n * d.Cout + co] = bsum;
+  }
+}
+
+// workspace bytes of the thin path, 0 when not eligible
+static size_t thin_wgrad_workspace(const lvae_conv_desc* d) {
+  const int K = d->KH * d->KW * d->C1;
+  if (d->gather != LVAE_GATHER_CONV || d->x2 != nullptr || d->C2 != 0 || d->in_scale != nullptr) return 0;
+  if (K > 76 || d->Cout > 64 || d->OH * d->OW > 1024 || d->N < 32 || d->N > 65535) return 0;
+  const size_t lds = ((size_t)((d->H + 2 * d->pad) * (d->W + 2 * d->pad) * d->C1 + 3) / 4 * 4 + (size_t)d->OH * d->OW * 64) * sizeof(float);
+  if (lds > 160 * 1024) return 0;
+  return (size_t)d->N * ((size_t)K * d->Cout + d->Cout) * sizeof(float);
+}
+
 size_t conv_wgrad_tile_workspace(const lvae_conv_desc* d);
 int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 
@@ -390,6 +466,8 @@ extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (wino) return wino;
   const size_t halo = conv_wgrad_tile_workspace(d);
   if (halo) return halo;
+  const size_t thin = thin_wgrad_workspace(d);
+  if (thin) return thin;
   int ksplit, pps, ncit, ncot;
   wgrad_plan(d, ksplit, pps, ncit, ncot);
   const size_t per = (size_t)d->KH * d->KW * (d->C1 + d->C2) * d->Cout + d->Cout;
@@ -411,6 +489,28 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   if (!halo_off && conv_wgrad_tile_workspace(d)) {
     const int hr = conv_wgrad_tile_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
+  }
+  if (!halo_off && thin_wgrad_workspace(d)) {
+    ThinWgradArgs ta;
+    ta.d = *d;
+    ta.dy = dy;
+    ta.K = d->KH * d->KW * d->C1;
+    ta.PH = d->H + 2 * d->pad;
+    ta.PW = d->W + 2 * d->pad;
+    ta.slab_w = static_cast<float*>(workspace);
+    ta.slab_b = db ? ta.slab_w + (size_t)d->N * ta.K * d->Cout : nullptr;
+    const size_t lds = ((size_t)(ta.PH * ta.PW * d->C1 + 3) / 4 * 4 + (size_t)d->OH * d->OW * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      LVAE_REQUIRE(e == hipSuccess, (int)e, "conv_wgrad_thin: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3(d->N), dim3(256), lds, (hipStream_t)stream, ta);
+    LVAE_LAUNCH_CHECK("conv_wgrad_thin");
+    wgrad_reduce_launch(ta.slab_w, ta.slab_b, d->N, d->KH * d->KW, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, (hipStream_t)stream);
+    LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
+    return 0;
   }
   WgradArgs a;
   a.d = *d;

@@ -43,6 +43,8 @@ CONV_CASES = [
     (5, 64, 64, 16, 16, 3, 2, 1),
     (3, 3, 64, 32, 32, 5, 2, 2),
     (2, 1, 16, 28, 28, 5, 2, 2),
+    (40, 3, 64, 32, 32, 5, 2, 2),    # stem: thin-input weight-gradient kernel (one workgroup per image)
+    (33, 1, 32, 28, 28, 5, 2, 2),
     (2, 64, 100, 32, 32, 3, 1, 1),
     (3, 64, 1, 28, 28, 3, 1, 1),
     (2, 16, 6, 16, 16, 3, 1, 1),
