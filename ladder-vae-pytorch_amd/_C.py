@@ -32,6 +32,8 @@ class ConvDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2  # LVAE_ABI_VERSION of include/lvae_hip.h
+
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); every symbol of include/lvae_hip.h
@@ -98,8 +100,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype, fn.argtypes = res, args
-    if lib.lvae_abi_version() != 2:
-        raise LvaeHipError("liblvae_hip.so ABI version %d, expected 2" % lib.lvae_abi_version())
+    if lib.lvae_abi_version() != ABI_VERSION:
+        raise LvaeHipError("liblvae_hip.so ABI version %d, expected %d" % (lib.lvae_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -24,8 +24,15 @@ def test_library_exports_every_declared_symbol():
     for name in syms:
         assert hasattr(lib, name), name
     assert sorted(_C.SIGNATURES) == syms  # the Python binding types exactly the declared surface
-    assert _C.load().lvae_abi_version() == 2
+    assert _C.load().lvae_abi_version() == _C.ABI_VERSION
     assert _C.load().lvae_last_error() is not None
+
+
+def test_abi_version_matches_header():
+    import lvae_amd  # noqa: F401
+    from lvae_amd import _C
+    hdr = open(os.path.join(ROOT, 'include', 'lvae_hip.h')).read()
+    assert int(re.search(r'#define LVAE_ABI_VERSION (\d+)', hdr).group(1)) == _C.ABI_VERSION
 
 
 def test_struct_layout_matches_header():
