@@ -437,6 +437,8 @@ static size_t thin_wgrad_workspace(const lvae_conv_desc* d) {
   return (size_t)d->N * ((size_t)K * d->Cout + d->Cout) * sizeof(float);
 }
 
+size_t conv1x1_wgrad_workspace(const lvae_conv_desc* d);
+int conv1x1_wgrad_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 size_t conv_wgrad_tile_workspace(const lvae_conv_desc* d);
 int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 
@@ -464,6 +466,8 @@ extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
   const size_t wino = conv_wgrad_wino_workspace(d);
   if (wino) return wino;
+  const size_t direct = conv1x1_wgrad_workspace(d);
+  if (direct) return direct;
   const size_t halo = conv_wgrad_tile_workspace(d);
   if (halo) return halo;
   const size_t thin = thin_wgrad_workspace(d);
@@ -484,6 +488,10 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
   if (!halo_off && conv_wgrad_wino_workspace(d)) {
     const int hr = conv_wgrad_wino_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
+  if (!halo_off && conv1x1_wgrad_workspace(d)) {
+    const int hr = conv1x1_wgrad_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
   }
   if (!halo_off && conv_wgrad_tile_workspace(d)) {
@@ -564,7 +572,8 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     wp += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
     const bool al = (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
     const bool wino = !halo_off && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
-    const bool groupable = !halo_off && !wino && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0;
+    const bool groupable = !halo_off && !wino && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
+                           conv1x1_wgrad_workspace(&descs[i]) == 0;
     // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
     kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < 65536 ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
                    : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1);

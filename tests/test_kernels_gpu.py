@@ -59,6 +59,8 @@ CONV_CASES = [
     (130, 64, 64, 16, 16, 3, 1, 1),
     (40, 128, 64, 16, 16, 1, 1, 0),  # 1x1 tile wgrad with two ci blocks
     (5, 64, 128, 4, 4, 1, 1, 0),
+    (130, 64, 128, 16, 16, 1, 1, 0),  # direct (no LDS staging) 1x1 weight gradient, 4 co blocks
+    (129, 64, 64, 16, 16, 1, 1, 0),   # ... 2 co blocks, ragged pixel ranges
 ]
 
 
