@@ -9,6 +9,8 @@
 //
 // 4 waves as 2(M) x 2(N); wave wn owns columns {ni*64 + wn*32 + lane} (ni = 0,1), so for the gate the a- and b-halves of
 // a channel sit in the same lane.
+#include <stdlib.h>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -194,7 +196,10 @@ static int launch_pw(const PwArgs& a, hipStream_t s) {
 
 template <int KT, int NT, bool KC>
 static int pick_bm(const PwArgs& a, hipStream_t s) {
-  return (a.M >= 128 * 192) ? launch_pw<128, KT, NT, KC>(a, s) : launch_pw<64, KT, NT, KC>(a, s);
+  static const int force = getenv("LVAE_PW_BM") ? atoi(getenv("LVAE_PW_BM")) : 0;  // tuning switch
+  if (force == 64) return launch_pw<64, KT, NT, KC>(a, s);
+  if (force == 128) return launch_pw<128, KT, NT, KC>(a, s);
+  return launch_pw<64, KT, NT, KC>(a, s);  // measured: 64-pixel tiles (2-3 workgroups per CU overlap load / MFMA / store) beat 128
 }
 
 // -1000: not eligible (the caller uses the generic kernel)
