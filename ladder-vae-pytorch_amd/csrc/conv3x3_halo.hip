@@ -32,7 +32,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   constexpr bool KG = BM == 32;
   constexpr int WMT = KG ? 32 : BM / 2, MI = WMT / 32;
   constexpr int CIN4 = CIN_T / 4;
-  constexpr int KS = 32;           // reduction channels per stage (half a tap at Cin = 64): keeps LDS <= 80 KB -> 2 WGs/CU
+  // reduction channels per stage: half a tap at Cin = 64 keeps LDS <= 80 KB -> 2 WGs/CU on the large tiles; the 32-pixel tile
+  // (low-resolution levels, latency bound, small halo) takes whole taps: 9 barrier-separated stages instead of 18
+  constexpr int KS = (BM == 32 && CIN_T >= 64) ? 64 : 32;
+  constexpr int NP = KS / 16;      // float4 of a weight stage per thread
   constexpr int KS4 = KS / 4;
   constexpr int LDB = KS + 4;      // k-contiguous B row stride
   constexpr int SPT = CIN_T / KS;  // stages per tap
@@ -59,21 +62,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   // ---- weight tile of one stage (tap, 32-channel half): global -> register ring (RING stages in flight) -> LDS.
   // One stage is only 16-32 MFMAs per wave (0.4-0.9 us), shorter than an L2 round trip, so loads run RING stages ahead.
   constexpr int RING = 3;
-  f32x4 breg[RING][2];
-  auto load_b = [&](int stage, f32x4 (&r)[2]) {
+  f32x4 breg[RING][NP];
+  auto load_b = [&](int stage, f32x4 (&r)[NP]) {
     const int tap = stage / SPT, k0 = (stage - tap * SPT) * KS;
     const float* wt = d.w + (int64_t)tap * d.w_stap;
     if (B_KCONTIG) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int n = (t >> 3) + 32 * p, k = k0 + (t & 7) * 4;
+      for (int p = 0; p < NP; ++p) {
+        const int n = t / KS4 + (256 / KS4) * p, k = k0 + (t % KS4) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (co0 + n < d.Cout && k < Cin) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)(co0 + n) * d.w_sn + k);
         r[p] = v;
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const int k = k0 + (t >> 4) + 16 * p, n = (t & 15) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < Cin && co0 + n < d.Cout) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d.w_sk + co0 + n);
@@ -81,14 +84,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
       }
     }
   };
-  auto store_b = [&](int buf, const f32x4 (&r)[2]) {
+  auto store_b = [&](int buf, const f32x4 (&r)[NP]) {
     float* Bb = Bs + buf * BBUF;
     if (B_KCONTIG) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(Bb + ((t >> 3) + 32 * p) * LDB + (t & 7) * 4) = r[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(Bb + (t / KS4 + (256 / KS4) * p) * LDB + (t % KS4) * 4) = r[p];
     } else {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(Bb + ((t >> 4) + 16 * p) * LDN + (t & 15) * 4) = r[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(Bb + ((t >> 4) + 16 * p) * LDN + (t & 15) * 4) = r[p];
     }
   };
 
@@ -276,7 +279,8 @@ static int launch_halo(HaloArgs a, hipStream_t s) {
     }
     attr_set = true;
   }
-  size_t lds = ((size_t)a.halo_px * (CIN_T + 4) + 2 * 64 * 36) * sizeof(float);
+  constexpr int ks = (BM == 32 && CIN_T >= 64) ? 64 : 32;
+  size_t lds = ((size_t)a.halo_px * (CIN_T + 4) + 2 * 64 * (ks + 4)) * sizeof(float);
   const size_t lds_out = (size_t)(BM == 32 ? 2 : 1) * BM * 68 * sizeof(float);  // epilogue staging tile(s)
   if (lds < lds_out) lds = lds_out;
   const int img_groups = (a.d.N + a.NI - 1) / a.NI;
