@@ -97,6 +97,14 @@ int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout
  * Supported: Cin <= 128, 2C <= 128, channel counts multiples of 4; otherwise LVAE_EINVAL (compose lvae_conv2d_f32 +
  * lvae_gate_fwd_f32 instead). */
 int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream);
+/* GateLayer2d backward fused with the dgrad of its 1x1 convolution (autograd of lib/nn.py:118-126): forms
+ *   dab[m,c] = dout*sigmoid(b)*act'(a) ; dab[m,C+c] = dout*act(a)*sigmoid(b)*(1-sigmoid(b))      (a, b = the halves of ab)
+ * in the kernel's operand staging (also written to `dab` [M,2C] when non-NULL: the weight gradient of the gate convolution
+ * reads it) and computes dx = dab . W^T with the descriptor's epilogue. `d` describes that dgrad exactly as for
+ * lvae_conv2d_f32 (C1 = 2C, transposed weight strides, y = dx, out_scale = dropout mask); d->x is ignored.
+ * Same shape limits as lvae_conv1x1_gate_f32, otherwise LVAE_EINVAL (compose lvae_gate_bwd_f32 + lvae_conv2d_f32). */
+int lvae_conv1x1_gate_bwd_f32(const lvae_conv_desc* d, const float* dout, const float* ab, int32_t act, float* dab,
+                              void* stream);
 
 /* Weight / bias gradient of the convolution described by `d` (d->y is unused, d->w gives only the strides):
  *   dw[tap,k,n] += sum_{n,oh,ow} T(x)[n,ih,iw,k] * dy[n,oh,ow,n]     db[n] += sum dy[..,n]

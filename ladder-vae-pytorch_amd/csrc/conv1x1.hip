@@ -21,6 +21,12 @@ struct PwArgs {
   const float* gate_res;  // [M][N/2] or null
   float* gate_out;        // [M][N/2] or null (null: plain convolution)
   int gate_act;
+  // gate backward fused as the A operand (K = 2C): A[m][k] = dab[m][k] computed from dout [M][C] and ab [M][2C]; also written
+  // to gb_dab (the weight gradient of the gate convolution reads it)
+  const float* gb_dout;
+  const float* gb_ab;
+  float* gb_dab;
+  int gb_act;
 };
 
 template <int BM, int KT, int NT, bool B_KCONTIG>
@@ -43,16 +49,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
   constexpr int APT = BM * K4 / 256;  // float4 of A per thread
   constexpr int BPT = NT * K4 / 256;  // float4 of B per thread (both layouts hold KT*NT floats)
   f32x4 av[APT], bv[BPT];
+  const bool gate_bwd = a.gb_dout != nullptr;
+  if (!gate_bwd) {
 #pragma unroll
-  for (int u = 0; u < APT; ++u) {
-    const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
-    const int m = m0 + r;
-    const bool ok = (m < a.M) & (k < K);
-    const bool first = k < d.C1;
-    const float* src = first ? d.x : d.x2;
-    const size_t off = ok ? (size_t)m * (first ? d.C1 : d.C2) + (first ? k : k - d.C1) : 0;
-    const f32x4 v = *reinterpret_cast<const f32x4*>((ok ? src : d.x) + off);
-    av[u] = ok ? v : zero4;
+    for (int u = 0; u < APT; ++u) {
+      const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
+      const int m = m0 + r;
+      const bool ok = (m < a.M) & (k < K);
+      const bool first = k < d.C1;
+      const float* src = first ? d.x : d.x2;
+      const size_t off = ok ? (size_t)m * (first ? d.C1 : d.C2) + (first ? k : k - d.C1) : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>((ok ? src : d.x) + off);
+      av[u] = ok ? v : zero4;
+    }
   }
 #pragma unroll
   for (int u = 0; u < BPT; ++u) {
@@ -69,14 +78,48 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       bv[u] = ok ? v : zero4;
     }
   }
+  if (!gate_bwd) {
 #pragma unroll
-  for (int u = 0; u < APT; ++u) {
-    const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
-    f32x4 v = av[u];
-    if (d.in_scale && m0 + r < a.M && k < K) {
-      v = act_fwd4(v * *reinterpret_cast<const f32x4*>(d.in_scale + k) + *reinterpret_cast<const f32x4*>(d.in_shift + k), d.in_act);
+    for (int u = 0; u < APT; ++u) {
+      const int idx = t + 256 * u, r = idx / K4, k = (idx - r * K4) * 4;
+      f32x4 v = av[u];
+      if (d.in_scale && m0 + r < a.M && k < K) {
+        v = act_fwd4(v * *reinterpret_cast<const f32x4*>(d.in_scale + k) + *reinterpret_cast<const f32x4*>(d.in_shift + k), d.in_act);
+      }
+      *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
     }
-    *reinterpret_cast<f32x4*>(As + r * LDA + k) = v;
+  } else {
+    // dab[:, c] = dout * sigmoid(b) * act'(a) ; dab[:, C + c] = dout * act(a) * sigmoid(b) * (1 - sigmoid(b))   (lib/nn.py:121-126)
+    const int C = K >> 1;
+    for (int idx = t; idx < BM * (KT / 8); idx += 256) {
+      const int r = idx / (KT / 8), c = (idx - r * (KT / 8)) * 4;
+      const int m = m0 + r;
+      if (c >= C) continue;
+      f32x4 lo = zero4, hi = zero4;
+      if (m < a.M) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.gb_dout + (size_t)m * C + c);
+        const f32x4 av4 = *reinterpret_cast<const f32x4*>(a.gb_ab + (size_t)m * K + c);
+        const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.gb_ab + (size_t)m * K + C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(bv4[j]);
+          lo[j] = g[j] * sg * act_grad(av4[j], a.gb_act);
+          hi[j] = g[j] * act_fwd(av4[j], a.gb_act) * sg * (1.f - sg);
+        }
+        if (a.gb_dab) {
+          *reinterpret_cast<f32x4*>(a.gb_dab + (size_t)m * K + c) = lo;
+          *reinterpret_cast<f32x4*>(a.gb_dab + (size_t)m * K + C + c) = hi;
+        }
+      }
+      *reinterpret_cast<f32x4*>(As + r * LDA + c) = lo;
+      *reinterpret_cast<f32x4*>(As + r * LDA + C + c) = hi;
+    }
+    // columns [2C, KT) of the tile (K < KT) must read as zero
+    if (K < KT)
+      for (int idx = t; idx < BM * ((KT - K) / 4); idx += 256) {
+        const int r = idx / ((KT - K) / 4), k = K + (idx - r * ((KT - K) / 4)) * 4;
+        *reinterpret_cast<f32x4*>(As + r * LDA + k) = zero4;
+      }
   }
 #pragma unroll
   for (int u = 0; u < BPT; ++u) {
@@ -203,10 +246,12 @@ static int pick_bm(const PwArgs& a, hipStream_t s) {
 }
 
 // -1000: not eligible (the caller uses the generic kernel)
-int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s) {
+int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
+                   const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s) {
   const int K = d->C1 + d->C2, N = d->Cout;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W) return -1000;
   if (K > 128 || N > 128 || d->C1 % 4 || d->C2 % 4 || N % 4 || (gate_out && N % 8)) return -1000;
+  if (gb_dout && (K % 8 || d->C2 != 0 || d->in_scale != nullptr || !al16p(gb_dout) || !al16p(gb_ab) || !al16p(gb_dab))) return -1000;
   if (!al16p(d->x) || !al16p(d->x2) || !al16p(d->w) || !al16p(d->y) || !al16p(d->bias) || !al16p(d->in_scale) ||
       !al16p(d->in_shift) || !al16p(d->out_scale) || !al16p(gate_res) || !al16p(gate_out))
     return -1000;
@@ -222,6 +267,10 @@ int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out,
   a.gate_res = gate_res;
   a.gate_out = gate_out;
   a.gate_act = gate_act;
+  a.gb_dout = gb_dout;
+  a.gb_ab = gb_ab;
+  a.gb_dab = gb_dab;
+  a.gb_act = gb_act;
   const bool k64 = K <= 64, n64 = N <= 64;
   if (nc) {
     if (k64) return n64 ? pick_bm<64, 64, false>(a, s) : pick_bm<64, 128, false>(a, s);
@@ -229,6 +278,10 @@ int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out,
   }
   if (k64) return n64 ? pick_bm<64, 64, true>(a, s) : pick_bm<64, 128, true>(a, s);
   return n64 ? pick_bm<128, 64, true>(a, s) : pick_bm<128, 128, true>(a, s);
+}
+
+int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s) {
+  return conv1x1_try_ex(d, gate_res, gate_out, gate_act, nullptr, nullptr, nullptr, 0, s);
 }
 
 }  // namespace lvae

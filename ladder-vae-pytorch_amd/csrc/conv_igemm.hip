@@ -358,6 +358,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d);
 bool conv3x3_wino_eligible(const lvae_conv_desc* d);
 int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s);
+int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
+                   const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -419,5 +421,24 @@ extern "C" int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, 
   LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
                "lvae_conv1x1_gate_f32: unsupported shape (needs a 1x1 stride-1 conv, Cin <= 128, Cout <= 128, channels %% 4 == 0, "
                "16-byte aligned buffers); use lvae_conv2d_f32 + lvae_gate_fwd_f32");
+  return rc;
+}
+
+// GateLayer2d backward fused with the dgrad of its 1x1 convolution: dab (the gradient w.r.t. the pre-activations ab, also
+// written to `dab` for the weight-gradient call) is formed in the kernel's operand staging from dout and ab, then
+// dx = dab . W^T with the descriptor's epilogue (out_scale = Dropout2d mask of the producer). `d` describes that dgrad:
+// C1 = 2C, Cout = channels of the gate convolution's input, d->x is ignored.
+extern "C" int lvae_conv1x1_gate_bwd_f32(const lvae_conv_desc* d, const float* dout, const float* ab, int32_t act, float* dab,
+                                         void* stream) {
+  LVAE_REQUIRE(d && dout && ab && d->y, LVAE_EINVAL, "lvae_conv1x1_gate_bwd_f32: null pointer");
+  lvae_conv_desc dd = *d;
+  dd.x = ab;  // any valid, aligned device pointer: the A operand is computed, not loaded
+  int rc = conv_desc_check(&dd, "lvae_conv1x1_gate_bwd_f32");
+  if (rc) return rc;
+  LVAE_REQUIRE(dd.C1 % 8 == 0 && dd.C2 == 0, LVAE_EINVAL, "lvae_conv1x1_gate_bwd_f32: C1 must be 2C");
+  rc = conv1x1_try_ex(&dd, nullptr, nullptr, 0, dout, ab, dab, act, (hipStream_t)stream);
+  LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
+               "lvae_conv1x1_gate_bwd_f32: unsupported shape (needs a 1x1 stride-1 conv, 2C <= 128, Cout <= 128, 16-byte aligned "
+               "buffers); use lvae_gate_bwd_f32 + lvae_conv2d_f32");
   return rc;
 }

@@ -182,6 +182,23 @@ def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True):
     return ab, out
 
 
+def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):
+    """Backward of conv1x1_gate w.r.t. the convolution input and the pre-activations: returns (dab, dx). One kernel when the
+    shape is supported (gate backward formed in the dgrad kernel's operand staging), else gate_bwd + conv2d_dgrad."""
+    _chk_nhwc(dout, 'dout')
+    N, H, W, Cn = dout.shape
+    fused_ok = (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cout == 2 * Cn and
+                g.Cout <= 128 and g.Cin <= 128 and g.Cout % 8 == 0 and g.Cin % 4 == 0 and (g.s_co == 1 or g.s_ci == 1))
+    if not fused_ok:
+        dab = gate_bwd(dout, ab, act)
+        return dab, conv2d_dgrad(dab, weight, g, (H, W), out_scale=out_scale)
+    dab = torch.empty_like(ab)
+    dx = torch.empty((N, H, W, g.Cin), dtype=torch.float32, device=dout.device)
+    d = _desc(g, weight, ab, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
+    call('lvae_conv1x1_gate_bwd_f32', C.byref(d), ptr(dout), ptr(ab), ACT[act], ptr(dab), stream_ptr())
+    return dab, dx
+
+
 def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
     """Gradient w.r.t. the conv input (before any fused input transform). dy NHWC (N,OH,OW,Cout) -> (N,H,W,Cin).
     out_scale (N,Cin) multiplies the result per (sample, channel) (Dropout2d mask of the producer).

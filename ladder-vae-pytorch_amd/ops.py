@@ -194,9 +194,8 @@ class ResBlockFn(Function):
         hw = (x.shape[1], x.shape[2])
         if blk.gate is not None:
             gw = blk.gate.weight
-            dab = K.gate_bwd(dout, ab, act)
+            dab, dy2 = K.conv1x1_gate_bwd(dout, ab, gw, blk.gate.geom(), act, out_scale=m2)
             wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
-            dy2 = K.conv2d_dgrad(dab, gw, blk.gate.geom(), hw, out_scale=m2)
         else:
             dy2 = K.scale_rows_add(dout, m2, None) if m2 is not None else dout
         # second half

@@ -293,6 +293,30 @@ def test_conv1x1_gate_fused(K, shape):
     assert rel(nchw(abd), ab) < 2e-6 and rel(nchw(outd), out) < 2e-6
 
 
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8), (5, 8, 2, 2)])
+def test_conv1x1_gate_bwd_fused(K, shape):
+    """gate backward + 1x1 dgrad in one kernel == lvae_gate_bwd_f32 followed by lvae_conv2d_f32 (and both == autograd)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C))
+    b = torch.randn(2 * C, generator=g)
+    ab = F.conv2d(x, w, b)
+    a_, b_ = ab.chunk(2, 1)
+    out = F.elu(a_) * torch.sigmoid(b_)
+    dout = torch.randn(out.shape, generator=g)
+    mask = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
+    out.backward(dout)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 0)
+    abd, doutd = nhwc(ab.detach()), nhwc(dout)
+    dab, dx = K.conv1x1_gate_bwd(doutd, abd, wp, geom, 'elu', out_scale=mask.cuda())
+    dab_ref = K.gate_bwd(doutd, abd, 'elu')
+    assert rel(dab, dab_ref) < 1e-6
+    assert rel(dx, K.conv2d_dgrad(dab_ref, wp, geom, (H, W), out_scale=mask.cuda())) < 2e-6
+    assert rel(nchw(dx), x.grad * mask.view(N, C, 1, 1)) < 3e-6
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
