@@ -384,12 +384,23 @@ __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* a, con
   }
 }
 
+// 64 columns per workgroup, the four waves take interleaved rows (fixed order) and meet in LDS: a (256, 256) input used to
+// be ONE workgroup walking 256 dependent row loads (56 us)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t R, int64_t P, float* out, int accumulate) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int64_t r = 0; r < R; ++r) s += x[r * P + p];
-  out[p] = accumulate ? out[p] + s : s;
+  if (p < P) {
+#pragma unroll 8
+    for (int64_t r = wv; r < R; r += 4) s += x[r * P + p];
+  }
+  red[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && p < P) {
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[p] = accumulate ? out[p] + s : s;
+  }
 }
 
 static bool vec_ok(int C, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
@@ -567,7 +578,7 @@ extern "C" int lvae_scale_rows_add_f32(const float* a, const float* row_scale, i
 
 extern "C" int lvae_colsum_f32(const float* x, int64_t R, int64_t P, float* out, int32_t accumulate, void* stream) {
   LVAE_REQUIRE(x && out && R > 0 && P > 0, LVAE_EINVAL, "lvae_colsum_f32: bad args");
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, R, P, out,
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, R, P, out,
                      accumulate);
   LVAE_LAUNCH_CHECK("colsum");
   return 0;

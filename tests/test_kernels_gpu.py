@@ -317,6 +317,18 @@ def test_conv1x1_gate_bwd_fused(K, shape):
     assert rel(nchw(dx), x.grad * mask.view(N, C, 1, 1)) < 3e-6
 
 
+@pytest.mark.parametrize('shape', [(256, 256), (7, 70), (1, 3), (300, 1)])
+def test_colsum(K, shape):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(shape, generator=g)
+    out0 = torch.randn(shape[1], generator=g)
+    out = out0.cuda()
+    K.colsum(x.cuda(), out, True)
+    torch.testing.assert_close(out.cpu(), out0 + x.sum(0), rtol=1e-5, atol=1e-5)
+    K.colsum(x.cuda(), out, False)
+    torch.testing.assert_close(out.cpu(), x.sum(0), rtol=1e-5, atol=1e-5)
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
