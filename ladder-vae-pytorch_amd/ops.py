@@ -285,6 +285,7 @@ class NormalStochFn(Function):
     @staticmethod
     def forward(ctx, p, q, noise, mode, analytical, Z, N):
         z, lp, lq, kl, ks = K.normal_stochastic_fwd(p, q, noise, mode, analytical, Z, N)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernel takes NULL) instead of zero-filled tensors
         ctx.mode, ctx.analytical, ctx.Z = mode, analytical, Z
         ctx.has_q = q is not None
         ctx.p_bcast = p.shape[0] == 1 and N > 1
@@ -297,6 +298,8 @@ class NormalStochFn(Function):
     def backward(ctx, dz, g_lp, g_lq=None, g_kl=None, g_ks=None):
         p, q, eps, z = ctx.saved_tensors
         cc = lambda t: None if t is None else _c(t)
+        if dz is None and g_lp is None and g_lq is None and g_kl is None and g_ks is None:
+            return None, None, None, None, None, None, None
         dp, dq = K.normal_stochastic_bwd(p, q, eps, z, cc(dz), cc(g_lp), cc(g_lq), cc(g_kl), cc(g_ks), ctx.mode,
                                          ctx.analytical, ctx.Z)
         if ctx.p_bcast:
@@ -410,6 +413,7 @@ class KLBookFn(Function):
     @staticmethod
     def forward(ctx, kl_ln, free_bits):
         ctx.fb = free_bits
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(kl_ln)
         return K.kl_bookkeeping_fwd(kl_ln, free_bits)
 
@@ -417,6 +421,8 @@ class KLBookFn(Function):
     def backward(ctx, g_sep, g_avg, g_scal):
         (kl_ln,) = ctx.saved_tensors
         cc = lambda t: None if t is None else _c(t)
+        if g_sep is None and g_avg is None and g_scal is None:
+            return None, None
         return K.kl_bookkeeping_bwd(kl_ln, ctx.fb, cc(g_sep), cc(g_avg), cc(g_scal)), None
 
 
