@@ -240,3 +240,55 @@ def test_checkpoint_roundtrip_and_cli(tmp_path):
     ck2 = str(tmp_path / 'ck2.pt')
     lmain.main(argv + ['--steps', '5', '--log-every', '5', '--save-checkpoint', ck2])
     leval.main(argv + ['--ll', '--ll-samples', '4', '--n-test', '16', '--test-batch-size', '8', '--checkpoint', ck2])
+
+
+def test_large_batch_step_through_winograd_paths_matches_oracle():
+    """The golden vectors are tiny models whose layers stay below the Winograd / grouping thresholds. This step is big enough
+    (64 filters, batch 192, 16x16 and 8x8 levels) for the Winograd forward/dgrad/wgrad kernels, the prepared-weight cache, the
+    direct 1x1 weight gradient and the grouped weight gradients to run inside a real training step; loss, ELBO terms and every
+    parameter gradient are compared with the CPU oracle on the same weights, input and noise tape."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd import kernels as K
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import TapeNoise
+    from lvae_amd.optim import Adamax
+    from lvae_amd.engine import TrainStep
+    from oracle import lvae_ref as R
+    cfg = dict(color_ch=3, z_dims=[8, 8], blocks_per_layer=1, downsample=[0, 1], nonlin='elu', merge_type='residual',
+               batchnorm=True, stochastic_skip=True, n_filters=64, dropout=0.2, free_bits=1.0, learn_top_prior=True,
+               img_shape=(32, 32), likelihood_form='discr_log_mix', res_block_type='bacdbacd', gated=True,
+               no_initial_downscaling=False, analytical_kl=False)
+    torch.manual_seed(11)
+    model = LadderVAE(**cfg)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.floor(256 * torch.rand(192, 3, 32, 32)) / 255
+    tape = R.Tape(gen=torch.Generator().manual_seed(6))
+    pkeys = [k for k in sd if R.is_parameter_key(k)]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    fp, _ = R.forward_pass(sd, cfg, x, tape, param_keys=pkeys)
+    fp['loss'].backward()
+    model.cuda().train()
+    model.noise = TapeNoise(tape.entries)
+    opt = Adamax(model, lr=0.0)            # lr 0: the step leaves the weights (and the comparison) untouched
+    K.prepared.entries.clear()
+    K.prepared.table = None
+    step = TrainStep(model, opt, use_graph=False)
+    step(x.cuda())                          # registers the Winograd call sites (transforms their weights per launch)
+    assert len(K.prepared.entries) > 0, "no convolution took the Winograd path: the test does not cover what it claims"
+    model.noise = TapeNoise(tape.entries)
+    out = step(x.cuda())                    # second step: prepared (batched) weight transforms, same tape
+    torch.cuda.synchronize()
+    for k in ('loss', 'elbo', 'recons', 'kl'):
+        a, b = float(out[k]), float(fp[k])
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-3, (k, a, b)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = sd[k].grad
+        if ref is None or float(ref.norm()) < 1e-5:
+            continue
+        worst = max(worst, float((p.grad.cpu() - ref).norm() / ref.norm()))
+    assert worst < 5e-4, worst
+    K.prepared.entries.clear()
+    K.prepared.table = None
+
