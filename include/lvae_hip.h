@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 2
+#define LVAE_ABI_VERSION 3
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -74,6 +74,9 @@ typedef struct lvae_conv_desc {
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
   int32_t workspace_ready; /* non-zero: `workspace` already holds this descriptor's transformed weights (written by
                               lvae_conv2d_prepare_weights after the last change of w); the launch skips its own transform */
+  float* stats_out;       /* NULL, or [lvae_conv2d_stats_rows(d)][2][Cout]: per-workgroup partial BatchNorm statistics of the
+                              OUTPUT y: (sum(y - pivot), sum((y - pivot)^2)) per channel, for lvae_bn_finalize_parts_f32 */
+  const float* stats_pivot; /* [Cout] pivot of those sums (e.g. the running mean of the BatchNorm that consumes y) */
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -81,6 +84,11 @@ typedef struct lvae_conv_desc {
  * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
 size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+/* BatchNorm statistics of the convolution OUTPUT fused into the producing kernel's epilogue (saves the separate pass over y):
+ * rows of d->stats_out the launch will write, or 0 when the kernel variant this descriptor selects cannot produce them (then
+ * leave stats_out NULL and use lvae_bn_stats_f32 on y). Set workspace / workspace_bytes before asking: the answer depends on
+ * the variant. */
+int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d);
 
 /* Batched weight pre-transform: one launch for every convolution of a training step instead of one per convolution call.
  * For each descriptor with lvae_conv2d_workspace(d) > 0 give it a PRIVATE scratch buffer in d->workspace (kept until the
@@ -138,6 +146,12 @@ size_t lvae_bn_stats_workspace(int64_t M, int32_t C);
 int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                       float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+/* Finalize from per-workgroup partials written by a convolution epilogue (lvae_conv_desc.stats_out): parts [rows][2][C] with
+ * the pivot the producer used; same outputs and running-statistics update as lvae_bn_stats_f32 over M rows. `pivot` may alias
+ * running_mean (each channel's pivot is read before its running mean is updated). */
+int lvae_bn_finalize_parts_f32(const float* parts, int32_t rows, int64_t M, int32_t C, const float* pivot, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                               float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* Inference form: scale/shift from the running statistics. */
 int lvae_bn_eval_coeffs_f32(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, void* stream);

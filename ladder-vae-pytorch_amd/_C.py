@@ -28,11 +28,11 @@ class ConvDesc(C.Structure):
         ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
         ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32),
+        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p),
     ]
 
 
-ABI_VERSION = 2  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 3  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     'lvae_last_error': (C.c_char_p, []),
     'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv2d_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_prepare_entry_bytes': (_Z, []),
     'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_prepare_weights': (C.c_int, [_P, _I, _I, _P]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'lvae_conv2d_wgrad_grouped_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),
     'lvae_bn_stats_f32': (C.c_int, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    'lvae_bn_finalize_parts_f32': (C.c_int, [_P, _I, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'lvae_bn_eval_coeffs_f32': (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'lvae_affine_act_f32': (C.c_int, [_P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
     'lvae_affine_act_bwd_f32': (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),

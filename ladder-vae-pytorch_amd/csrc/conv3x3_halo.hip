@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     // tile pixel p of a tile that covers whole rows / whole images is pixel (n0*H + oh0)*W + p of the tensor: the output
     // pointer is linear in p (16 pixel rows per pass), only the image index needs a division (for N bound and dropout)
     const int c4 = (t & 15) * 4, col = co0 + c4;
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;  // BatchNorm partials of the stored values (d.stats_out)
+    if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
     if (col < d.Cout) {
       f32x4 bias = {0.f, 0.f, 0.f, 0.f};
       if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);  // Cout % 4 == 0 on this path
@@ -231,7 +233,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
           }
           v = act_fwd4(v, d.out_act);
           *reinterpret_cast<f32x4*>(yp + (size_t)q * 16 * d.Cout) = v;
+          const f32x4 dl = v - piv;
+          st1 += dl;
+          st2 += dl * dl;
         }
+      }
+    }
+    if (d.stats_out) {  // 16 pixel groups x 64 channels -> one row of partials per pixel tile (fixed order)
+      __syncthreads();  // the staging tile is dead
+      float* red = smem;
+      *reinterpret_cast<f32x4*>(red + (t >> 4) * 64 + c4) = st1;
+      *reinterpret_cast<f32x4*>(red + 1024 + (t >> 4) * 64 + c4) = st2;
+      __syncthreads();
+      if (t < 128) {
+        const int c = t & 63, which = t >> 6;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += red[which * 1024 + r * 64 + c];
+        if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
       }
     }
   }
@@ -290,30 +309,49 @@ static int launch_halo(HaloArgs a, hipStream_t s) {
   return 0;
 }
 
-// returns kHaloNotEligible when the descriptor does not fit this kernel (the caller then uses the generic one)
-int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
+// eligibility + tile plan: returns the tile size (128 / 64 / 32), 0 when the descriptor does not fit this kernel
+static int halo_select(const lvae_conv_desc* d, HaloArgs& a, bool& ncontig_out) {
   const int Cin = d->C1;
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return kHaloNotEligible;
-  if (Cin > 64 || Cin % 4 != 0 || !al16(d->x) || !al16(d->w) || d->w_stap % 4 != 0) return kHaloNotEligible;
-  if ((int64_t)d->N * d->H * d->W * Cin >= ((int64_t)1 << 31)) return kHaloNotEligible;  // 32-bit element offsets in the halo loader
-  if (d->in_scale && (!al16(d->in_scale) || !al16(d->in_shift))) return kHaloNotEligible;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return 0;
+  if (Cin > 64 || Cin % 4 != 0 || !al16(d->x) || !al16(d->w) || d->w_stap % 4 != 0) return 0;
+  if ((int64_t)d->N * d->H * d->W * Cin >= ((int64_t)1 << 31)) return 0;  // 32-bit element offsets in the halo loader
+  if (d->in_scale && (!al16(d->in_scale) || !al16(d->in_shift))) return 0;
   const bool kcontig = d->w_sk == 1 && d->w_sn % 4 == 0;
   const bool ncontig = d->w_sn == 1 && d->w_sk % 4 == 0 && d->Cout % 4 == 0;
-  if (!kcontig && !ncontig) return kHaloNotEligible;
-  if (d->Cout % 4 != 0 || !al16(d->y) || (d->bias && !al16(d->bias)) || (d->out_scale && !al16(d->out_scale))) return kHaloNotEligible;
+  if (!kcontig && !ncontig) return 0;
+  if (d->Cout % 4 != 0 || !al16(d->y) || (d->bias && !al16(d->bias)) || (d->out_scale && !al16(d->out_scale))) return 0;
+  if (d->stats_out && (!al16(d->stats_pivot) || d->stats_pivot == nullptr)) return 0;
   const int cin_t = Cin <= 32 ? 32 : 64;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  HaloArgs a;
   a.d = *d;
   a.Cin = Cin;
   a.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
-  static const int dbg = getenv("LVAE_HALO_DEBUG") ? atoi(getenv("LVAE_HALO_DEBUG")) : 0;  // phase-skip switch, profiling only
-  a.debug = dbg;
   int BM = M >= 128 * 192 ? 128 : (M > 64 * 256 ? 64 : 32);
   while (!halo_plan(d->N, d->H, d->W, BM, cin_t, a)) {
-    if (BM == 32) return kHaloNotEligible;
+    if (BM == 32) return 0;
     BM /= 2;
   }
+  ncontig_out = ncontig;
+  return BM;
+}
+
+// rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
+int conv3x3_halo_stats_rows(const lvae_conv_desc* d) {
+  HaloArgs a;
+  bool nc;
+  if (!halo_select(d, a, nc)) return 0;
+  return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
+}
+
+// returns kHaloNotEligible when the descriptor does not fit this kernel (the caller then uses the generic one)
+int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
+  HaloArgs a;
+  bool ncontig = false;
+  const int BM = halo_select(d, a, ncontig);
+  if (BM == 0) return kHaloNotEligible;
+  const int cin_t = d->C1 <= 32 ? 32 : 64;
+  static const int dbg = getenv("LVAE_HALO_DEBUG") ? atoi(getenv("LVAE_HALO_DEBUG")) : 0;  // phase-skip switch, profiling only
+  a.debug = dbg;
   // n-contiguous weights take precedence when both hold (Cin == 1 cannot reach here)
   const bool kc = !ncontig;
   if (BM == 128) {

@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   __syncthreads();
   {
     const int c4 = (t & 15) * 4, col = co0 + c4;
+    f32x4 st1 = zero4, st2 = zero4, piv = zero4;  // BatchNorm partials of the stored values (d.stats_out)
+    if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
     if (col < d.Cout) {
       f32x4 bias = zero4;
       if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
@@ -289,7 +291,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
           *reinterpret_cast<f32x4*>(yb + (size_t)p * d.Cout) = v;
+          const f32x4 dl = v - piv;
+          st1 += dl;
+          st2 += dl * dl;
         }
+      }
+    }
+    if (d.stats_out) {  // 16 pixel groups x 64 channels -> one row of partials per pixel tile (fixed order)
+      __syncthreads();  // R is dead
+      float* red = smem;
+      *reinterpret_cast<f32x4*>(red + (t >> 4) * 64 + c4) = st1;
+      *reinterpret_cast<f32x4*>(red + 1024 + (t >> 4) * 64 + c4) = st2;
+      __syncthreads();
+      if (t < 128) {
+        const int c = t & 63, which = t >> 6;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += red[which * 1024 + r * 64 + c];
+        if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
       }
     }
   }
@@ -315,6 +334,21 @@ bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
   static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 192;  // tuning switch
   if (M < min_m || M * 128 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
   return true;
+}
+
+// rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
+int conv3x3_wino_stats_rows(const lvae_conv_desc* d) {
+  if (d->workspace == nullptr || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
+  int TH = 0;
+  for (int c = 2; c <= d->H; c += 2)
+    if (d->H % c == 0 && c * d->W <= 128) TH = c;
+  if (TH == 0) return 0;
+  int NI = TH < d->H ? 1 : 128 / (TH * d->W);
+  if (NI < 1) NI = 1;
+  if (NI > d->N) NI = d->N;
+  if (NI * (TH + 2) * (d->W + 2) > 256) return 0;
+  if ((size_t)NI * (TH + 2) * (d->W + 2) * ((d->C1 <= 64 ? 64 : 128) + 4) * sizeof(float) > 160 * 1024) return 0;
+  return ((d->N + NI - 1) / NI) * (d->H / TH);
 }
 
 // -1000: not eligible. `workspace` must hold conv3x3_wino_workspace(d) bytes (the transformed weights).

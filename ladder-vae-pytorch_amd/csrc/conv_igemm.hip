@@ -354,6 +354,8 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
 }
 
 int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s);
+int conv3x3_halo_stats_rows(const lvae_conv_desc* d);
+int conv3x3_wino_stats_rows(const lvae_conv_desc* d);
 int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d);
 bool conv3x3_wino_eligible(const lvae_conv_desc* d);
@@ -372,10 +374,20 @@ extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
   return conv3x3_wino_eligible(d) ? conv3x3_wino_workspace(d) : 0;
 }
 
+extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
+  if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
+  const int w = conv3x3_wino_stats_rows(d);
+  if (w > 0) return w;
+  if (d->workspace != nullptr && conv3x3_wino_eligible(d) && (size_t)d->workspace_bytes >= conv3x3_wino_workspace(d)) return 0;
+  return conv3x3_halo_stats_rows(d);
+}
+
 extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv2d_f32");
   if (rc) return rc;
   LVAE_REQUIRE(d->y != nullptr, LVAE_EINVAL, "lvae_conv2d_f32: null y");
+  LVAE_REQUIRE(d->stats_out == nullptr || (d->stats_pivot != nullptr && lvae_conv2d_stats_rows(d) > 0), LVAE_EINVAL,
+               "lvae_conv2d_f32: stats_out set but lvae_conv2d_stats_rows(d) == 0 (this kernel variant has no statistics epilogue)");
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
   if (!halo_off) {
     int hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);

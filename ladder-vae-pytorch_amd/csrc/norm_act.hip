@@ -444,6 +444,18 @@ extern "C" int lvae_bn_stats_f32(const float* x, int64_t M, int32_t C, const flo
   return 0;
 }
 
+extern "C" int lvae_bn_finalize_parts_f32(const float* parts, int32_t rows, int64_t M, int32_t C, const float* pivot,
+                                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                          float* running_var, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  LVAE_REQUIRE(parts && pivot && scale && shift && mean && rstd && rows > 0 && M > 0 && C > 0, LVAE_EINVAL,
+               "lvae_bn_finalize_parts_f32: bad arguments");
+  LVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), LVAE_EINVAL, "lvae_bn_finalize_parts_f32: running pair");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, parts, rows, C, M, pivot, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, mean, rstd);
+  LVAE_LAUNCH_CHECK("bn_finalize_parts");
+  return 0;
+}
+
 extern "C" int lvae_bn_eval_coeffs_f32(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                        const float* running_var, float eps, float* scale, float* shift, void* stream) {
   LVAE_REQUIRE(C > 0 && running_mean && running_var && scale && shift, LVAE_EINVAL, "lvae_bn_eval_coeffs_f32: bad args");

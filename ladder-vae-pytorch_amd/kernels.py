@@ -146,8 +146,11 @@ def _conv_ws(d, weight, device):
         prepared.attach(d, weight, device, need)
 
 
-def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None):
-    """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC."""
+def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None,
+           stats_pivot=None):
+    """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC.
+    stats_pivot (Cout,): also ask the kernel's epilogue for BatchNorm partials of y around that pivot; returns (y, parts) with
+    parts (rows, 2, Cout) for bn_finalize_parts, or (y, None) when the kernel variant chosen for this shape has no such epilogue."""
     _chk_nhwc(x, 'x')
     N, H, W, C1 = x.shape
     if x2 is not None:
@@ -160,8 +163,14 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
     _conv_ws(d, weight, x.device)
+    parts = None
+    if stats_pivot is not None:
+        rows = _C.load().lvae_conv2d_stats_rows(C.byref(d))
+        if rows > 0:
+            parts = torch.empty((rows, 2, g.Cout), dtype=torch.float32, device=x.device)
+            d.stats_out, d.stats_pivot = ptr(parts), ptr(stats_pivot)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
-    return y
+    return y if stats_pivot is None else (y, parts)
 
 
 def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True):
@@ -266,6 +275,16 @@ def bn_stats(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
     ws = workspace(need, x.device)
     call('lvae_bn_stats_f32', ptr(x), M, Cn, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean), ptr(running_var),
          ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), ws.data_ptr(), ws.numel(), stream_ptr())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_finalize_parts(parts, M, pivot, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """BatchNorm coefficients from the partials a convolution epilogue wrote (conv2d(..., stats_pivot=pivot)); same outputs and
+    running-statistics update as bn_stats. pivot may be running_mean itself."""
+    rows, _, Cn = parts.shape
+    out = torch.empty((4, Cn), dtype=torch.float32, device=parts.device)
+    call('lvae_bn_finalize_parts_f32', ptr(parts), rows, M, Cn, ptr(pivot), ptr(gamma), ptr(beta), eps, momentum,
+         ptr(running_mean), ptr(running_var), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), stream_ptr())
     return out[0], out[1], out[2], out[3]
 
 

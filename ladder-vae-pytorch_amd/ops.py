@@ -160,9 +160,13 @@ class ResBlockFn(Function):
         C = x.shape[3]
         st = []
         h = x
+        parts = None  # BatchNorm partials of h written by the epilogue of the convolution that produced it
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             if bn is not None:
-                if training:
+                if training and parts is not None:
+                    sc, sh, mean, rstd = K.bn_finalize_parts(parts, h.numel() // h.shape[3], bn.running_mean, bn.weight, bn.bias,
+                                                             bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+                elif training:
                     sc, sh, mean, rstd = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                                     bn.momentum)
                 else:
@@ -171,7 +175,12 @@ class ResBlockFn(Function):
             else:
                 sc, sh = _ones_zeros(C, dev)
                 mean = rstd = None
-            y = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m)
+            nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
+            if training and nxt is not None and nxt.running_mean is not None:
+                y, parts = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m,
+                                    stats_pivot=nxt.running_mean)
+            else:
+                y, parts = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m), None
             st.append((h, sc, sh, mean, rstd))
             h = y
         y2 = h

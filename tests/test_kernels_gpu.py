@@ -329,6 +329,30 @@ def test_colsum(K, shape):
     torch.testing.assert_close(out.cpu(), x.sum(0), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 32, 64, 8, 8), (9, 64, 100, 32, 32)])
+def test_bn_statistics_from_conv_epilogue(K, case):
+    """conv2d(..., stats_pivot) + bn_finalize_parts == conv2d followed by bn_stats on its output (Winograd and tile kernels)."""
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(44)
+    x = nhwc(torch.randn(N, Ci, H, W, generator=g))
+    wp = packed_weight(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = (torch.randn(Co, generator=g) + 2.0).cuda()          # output mean far from the pivot
+    drop = ((torch.rand(N, Co, generator=g) < 0.8).float() / 0.8).cuda()
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    rm, rv = (torch.randn(Co, generator=g) * 0.1).cuda(), (torch.rand(Co, generator=g) + 0.5).cuda()
+    rm2, rv2 = rm.clone(), rv.clone()
+    geom = K.ConvGeom(wp, 1, 1)
+    y, parts = K.conv2d(x, wp, geom, bias=b, out_scale=drop, stats_pivot=rm)
+    assert parts is not None, "this shape is meant to take a kernel with the statistics epilogue"
+    got = K.bn_finalize_parts(parts, N * H * W, rm, gamma, beta, rm, rv)
+    ref = K.bn_stats(y, gamma, beta, rm2, rv2)
+    for a_, b_ in zip(got, ref):
+        torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(rm, rm2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
+    assert torch.equal(y, K.conv2d(x, wp, geom, bias=b, out_scale=drop))
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
