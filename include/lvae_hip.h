@@ -105,6 +105,10 @@ int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout
  * Supported: Cin <= 128, 2C <= 128, channel counts multiples of 4; otherwise LVAE_EINVAL (compose lvae_conv2d_f32 +
  * lvae_gate_fwd_f32 instead). */
 int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream);
+/* With d->stats_out / d->stats_pivot ([C] pivot) set, lvae_conv1x1_gate_f32 also writes BatchNorm partials of `out` — the next
+ * residual block's BatchNorm input — as [lvae_conv1x1_gate_stats_rows(d)][2][C] for lvae_bn_finalize_parts_f32 (0 rows: not
+ * supported for this shape, leave stats_out NULL). */
+int32_t lvae_conv1x1_gate_stats_rows(const lvae_conv_desc* d);
 /* GateLayer2d backward fused with the dgrad of its 1x1 convolution (autograd of lib/nn.py:118-126): forms
  *   dab[m,c] = dout*sigmoid(b)*act'(a) ; dab[m,C+c] = dout*act(a)*sigmoid(b)*(1-sigmoid(b))      (a, b = the halves of ab)
  * in the kernel's operand staging (also written to `dab` [M,2C] when non-NULL: the weight gradient of the gate convolution

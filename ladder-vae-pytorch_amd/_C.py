@@ -47,6 +47,7 @@ SIGNATURES = {
     'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_prepare_weights': (C.c_int, [_P, _I, _I, _P]),
     'lvae_conv1x1_gate_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P, _P]),
+    'lvae_conv1x1_gate_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv1x1_gate_bwd_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),

@@ -180,6 +180,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
   if (a.gate_out != nullptr) {
     // gate epilogue: C = N/2 channels; thread -> (pixel, 4 channels)
     const int C = N >> 1, c4n = C >> 2;  // float4 per output pixel
+    // BatchNorm partials of `out` (d.stats_out): 256 % c4n == 0, so a thread keeps the same channel group for all its rows
+    const bool stats = d.stats_out != nullptr && (256 % c4n) == 0;
+    f32x4 st1 = zero4, st2 = zero4, piv = zero4;
+    if (stats) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + (t % c4n) * 4);
     for (int idx = t; idx < BM * c4n; idx += 256) {
       const int r = idx / c4n, c = (idx - r * c4n) * 4;
       const int m = m0 + r;
@@ -199,6 +203,23 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       for (int j = 0; j < 4; ++j) o[j] *= sigmoidf_(vb[j]);
       if (a.gate_res) o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
       *reinterpret_cast<f32x4*>(a.gate_out + (size_t)m * C + c) = o;
+      const f32x4 dl = o - piv;
+      st1 += dl;
+      st2 += dl * dl;
+    }
+    if (stats) {  // 256 / c4n row groups x C channels -> one row of partials per workgroup (fixed order)
+      __syncthreads();  // the staging tile is dead
+      const int G = 256 / c4n;
+      float* red = smem;
+      *reinterpret_cast<f32x4*>(red + (t / c4n) * C + (t % c4n) * 4) = st1;
+      *reinterpret_cast<f32x4*>(red + G * C + (t / c4n) * C + (t % c4n) * 4) = st2;
+      __syncthreads();
+      if (t < 2 * C) {
+        const int c = t % C, which = t / C;
+        float v = 0.f;
+        for (int r = 0; r < G; ++r) v += red[which * G * C + r * C + c];
+        d.stats_out[((size_t)blockIdx.x * 2 + which) * C + c] = v;
+      }
     }
   } else {
     const int n4 = N >> 2;

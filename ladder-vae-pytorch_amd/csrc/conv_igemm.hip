@@ -424,11 +424,22 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
 // GateLayer2d forward fused with its 1x1 convolution and the residual add (lib/nn.py:118-126, 99):
 //   ab = conv1x1(T(x)) + bias  (written to d->y when non-null; needed by the backward)
 //   out[m, c] = act(ab[m, c]) * sigmoid(ab[m, C + c]) + res[m, c]
+// rows of BatchNorm partials ([rows][2][C], C = Cout/2) lvae_conv1x1_gate_f32 writes for its `out` when d->stats_out is set
+extern "C" int32_t lvae_conv1x1_gate_stats_rows(const lvae_conv_desc* d) {
+  if (d == nullptr || d->Cout % 8 != 0) return 0;
+  const int c4n = d->Cout / 8;
+  if (c4n <= 0 || 256 % c4n != 0 || d->Cout > 128) return 0;
+  return (int32_t)(((int64_t)d->N * d->H * d->W + 63) / 64);  // 64-pixel tiles
+}
+
 extern "C" int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv1x1_gate_f32");
   if (rc) return rc;
   LVAE_REQUIRE(out != nullptr, LVAE_EINVAL, "lvae_conv1x1_gate_f32: null out");
   LVAE_REQUIRE(d->Cout % 2 == 0, LVAE_EINVAL, "lvae_conv1x1_gate_f32: Cout must be 2*C");
+  LVAE_REQUIRE(d->stats_out == nullptr || (d->stats_pivot != nullptr && lvae_conv1x1_gate_stats_rows(d) > 0 &&
+                                           (reinterpret_cast<uintptr_t>(d->stats_pivot) & 15) == 0),
+               LVAE_EINVAL, "lvae_conv1x1_gate_f32: stats_out set but lvae_conv1x1_gate_stats_rows(d) == 0");
   rc = conv1x1_try(d, res, out, act, (hipStream_t)stream);
   LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
                "lvae_conv1x1_gate_f32: unsupported shape (needs a 1x1 stride-1 conv, Cin <= 128, Cout <= 128, channels %% 4 == 0, "

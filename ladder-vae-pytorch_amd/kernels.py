@@ -173,9 +173,11 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     return y if stats_pivot is None else (y, parts)
 
 
-def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True):
+def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True, stats_pivot=None):
     """GateLayer2d forward: ab = conv1x1(x) + bias (returned when need_ab), out = act(a) * sigmoid(b) + res, one kernel.
-    Falls back to conv2d + gate_fwd when the fused kernel does not support the shape."""
+    Falls back to conv2d + gate_fwd when the fused kernel does not support the shape.
+    stats_pivot (C,): also return BatchNorm partials of `out` (rows, 2, C) around that pivot, or None when unsupported:
+    returns (ab, out, parts)."""
     _chk_nhwc(x, 'x')
     N, H, W, _ = x.shape
     Cn = g.Cout // 2
@@ -183,12 +185,19 @@ def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True):
                 g.Cout <= 128 and g.Cin % 4 == 0 and g.Cout % 8 == 0 and (g.s_co == 1 or g.s_ci == 1))
     if not fused_ok:
         ab = conv2d(x, weight, g, bias=bias)
-        return ab, gate_fwd(ab, res, act)
+        out = gate_fwd(ab, res, act)
+        return (ab, out) if stats_pivot is None else (ab, out, None)
     ab = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=x.device) if need_ab else None
     out = torch.empty((N, H, W, Cn), dtype=torch.float32, device=x.device)
     d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV, bias, y=ab)
+    parts = None
+    if stats_pivot is not None:
+        rows = _C.load().lvae_conv1x1_gate_stats_rows(C.byref(d))
+        if rows > 0:
+            parts = torch.empty((rows, 2, Cn), dtype=torch.float32, device=x.device)
+            d.stats_out, d.stats_pivot = ptr(parts), ptr(stats_pivot)
     call('lvae_conv1x1_gate_f32', C.byref(d), ptr(res), ACT[act], ptr(out), stream_ptr())
-    return ab, out
+    return (ab, out) if stats_pivot is None else (ab, out, parts)
 
 
 def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):

@@ -6,6 +6,8 @@ Functions return None for parameter inputs; activations flow through autograd no
 
 All activations are NHWC (N,H,W,C) contiguous float32 CUDA tensors.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -142,6 +144,9 @@ def conv(x, mod, x2=None, out_act=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+_GATE_STATS = os.environ.get('LVAE_NO_GATE_STATS') is None  # A/B switch, profiling only
+
+
 class ResBlockFn(Function):
     """Whole pre-activation residual block ('bacdbacd' / 'bacdbac' recipes of lib/nn.py:64-89, with or without
     BatchNorm, Dropout2d and the gate) as ONE autograd node:
@@ -160,12 +165,14 @@ class ResBlockFn(Function):
         C = x.shape[3]
         st = []
         h = x
-        parts = None  # BatchNorm partials of h written by the epilogue of the convolution that produced it
+        # BatchNorm partials of h written by the epilogue of the kernel that produced it: for x by the previous block's gate
+        # kernel (handed over through blk._in_parts by lib/nn.py), for conv1's output by conv1 itself
+        parts, pivot_in = blk.__dict__.pop('_in_parts', None) or (None, None)
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             if bn is not None:
                 if training and parts is not None:
-                    sc, sh, mean, rstd = K.bn_finalize_parts(parts, h.numel() // h.shape[3], bn.running_mean, bn.weight, bn.bias,
-                                                             bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+                    sc, sh, mean, rstd = K.bn_finalize_parts(parts, h.numel() // h.shape[3], pivot_in if i == 0 else bn.running_mean,
+                                                             bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
                 elif training:
                     sc, sh, mean, rstd = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                                     bn.momentum)
@@ -185,8 +192,18 @@ class ResBlockFn(Function):
             h = y
         y2 = h
         ab = None
+        blk.__dict__['_out_parts'] = None
         if blk.gate is not None:
-            ab, out = K.conv1x1_gate(y2, blk.gate.weight, blk.gate.geom(), blk.gate.bias, x, act)
+            if training and blk.bn1 is not None and blk.bn1.running_mean is not None and _GATE_STATS:
+                # the block output is (usually) the next block's BatchNorm input: statistics in the gate kernel's epilogue, around
+                # this block's own running mean (same residual stream: a pivot inside the data range); the copy keeps the pivot
+                # fixed when this block's statistics are updated before the consumer's finalize reads it
+                pivot = st[0][3].detach() if st[0][3] is not None else blk.bn1.running_mean.clone()
+                ab, out, oparts = K.conv1x1_gate(y2, blk.gate.weight, blk.gate.geom(), blk.gate.bias, x, act, stats_pivot=pivot)
+                if oparts is not None:
+                    blk.__dict__['_out_parts'] = (oparts, pivot)
+            else:
+                ab, out = K.conv1x1_gate(y2, blk.gate.weight, blk.gate.geom(), blk.gate.bias, x, act)
         else:
             out = K.add(y2, x)
         ctx.blk, ctx.training = blk, training

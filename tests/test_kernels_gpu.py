@@ -353,6 +353,28 @@ def test_bn_statistics_from_conv_epilogue(K, case):
     assert torch.equal(y, K.conv2d(x, wp, geom, bias=b, out_scale=drop))
 
 
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8)])
+def test_bn_statistics_from_gate_epilogue(K, shape):
+    """conv1x1_gate(..., stats_pivot) + bn_finalize_parts == bn_stats on the gate output (the next block's BatchNorm input)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(45)
+    x, res = nhwc(torch.randn(N, C, H, W, generator=g)), nhwc(torch.randn(N, C, H, W, generator=g) + 1.5)
+    wp = packed_weight(torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C))
+    b = torch.randn(2 * C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    rm2, rv2 = rm.clone(), rv.clone()
+    pivot = torch.randn(C, generator=g).cuda()
+    ab, out, parts = K.conv1x1_gate(x, wp, K.ConvGeom(wp, 1, 0), b, res, 'elu', stats_pivot=pivot)
+    assert parts is not None
+    got = K.bn_finalize_parts(parts, N * H * W, pivot, gamma, beta, rm, rv)
+    ref = K.bn_stats(out, gamma, beta, rm2, rv2)
+    for a_, b_ in zip(got, ref):
+        torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(rm, rm2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
