@@ -24,13 +24,14 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 3
+#define LVAE_ABI_VERSION 4
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
 #define LVAE_EWORKSPACE (-3) /* workspace too small */
 
 /* activation ids shared by every kernel (models/lvae.py:64-69 nonlin table) */
+enum { LVAE_STATS_BN_FWD = 0, LVAE_STATS_BN_BWD = 1 };
 enum { LVAE_ACT_NONE = 0, LVAE_ACT_ELU = 1, LVAE_ACT_RELU = 2, LVAE_ACT_LEAKYRELU = 3, LVAE_ACT_SELU = 4 };
 
 /* spatial gather of an implicit-GEMM convolution */
@@ -77,6 +78,13 @@ typedef struct lvae_conv_desc {
   float* stats_out;       /* NULL, or [lvae_conv2d_stats_rows(d)][2][Cout]: per-workgroup partial BatchNorm statistics of the
                               OUTPUT y: (sum(y - pivot), sum((y - pivot)^2)) per channel, for lvae_bn_finalize_parts_f32 */
   const float* stats_pivot; /* [Cout] pivot of those sums (e.g. the running mean of the BatchNorm that consumes y) */
+  /* stats_mode = LVAE_STATS_BN_BWD: y is the gradient dh w.r.t. h = act(x*scale + shift) of a training-mode BatchNorm; the
+   * epilogue writes the partials of that BatchNorm's backward, (sum g, sum g*xhat) with g = y * act'(x*scale+shift) and
+   * xhat = (x - mean)*rstd, to stats_out for lvae_affine_act_bwd_parts_f32. stats_x = x [N,OH,OW,Cout]; stats_pivot then points to
+   * the [4][Cout] coefficient block (scale, shift, mean, rstd) as written by lvae_bn_stats_f32 into consecutive arrays. */
+  int32_t stats_mode;     /* LVAE_STATS_BN_FWD (0, the default) or LVAE_STATS_BN_BWD */
+  int32_t stats_act;      /* activation of that BatchNorm block (mode LVAE_STATS_BN_BWD) */
+  const float* stats_x;
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -174,6 +182,13 @@ int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t M, int32_t 
                             const float* shift, int32_t act, int32_t bn_train, const float* mean, const float* rstd,
                             float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n, const float* add,
                             float* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* The training-mode case with the reduction already done by the epilogue of the convolution that produced dh
+ * (lvae_conv_desc.stats_mode = LVAE_STATS_BN_BWD, parts [rows][2][C]): finalize + apply, two launches.
+ * workspace: 2*C floats. */
+int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, const float* dh, const float* x, int64_t M, int32_t C,
+                                  const float* scale, const float* shift, int32_t act, const float* mean, const float* rstd,
+                                  float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n, const float* add,
+                                  float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GateLayer2d epilogue + residual add — lib/nn.py:121-126 and lib/nn.py:99

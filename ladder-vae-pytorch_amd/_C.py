@@ -28,11 +28,12 @@ class ConvDesc(C.Structure):
         ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
         ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p),
+        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p), ('stats_mode', C.c_int32), ('stats_act', C.c_int32),
+        ('stats_x', C.c_void_p),
     ]
 
 
-ABI_VERSION = 3  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 4  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     'lvae_bn_eval_coeffs_f32': (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'lvae_affine_act_f32': (C.c_int, [_P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
     'lvae_affine_act_bwd_f32': (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
+    'lvae_affine_act_bwd_parts_f32': (C.c_int, [_P, _I, _P, _P, _L, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
     'lvae_gate_fwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'lvae_gate_bwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'lvae_act_bwd_from_out_f32': (C.c_int, [_P, _P, _L, _I, _P, _P]),

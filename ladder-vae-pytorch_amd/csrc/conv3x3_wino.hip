@@ -268,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int c4 = (t & 15) * 4, col = co0 + c4;
     f32x4 st1 = zero4, st2 = zero4, piv = zero4;  // BatchNorm partials of the stored values (d.stats_out)
     if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
+    f32x4 bsh = piv, bmu = piv, brs = piv;  // LVAE_STATS_BN_BWD: piv = scale, then shift, mean, rstd of the [4][Cout] block
+    if (d.stats_out && d.stats_mode == LVAE_STATS_BN_BWD && col < d.Cout) {
+      bsh = *reinterpret_cast<const f32x4*>(d.stats_pivot + d.Cout + col);
+      bmu = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col);
+      brs = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col);
+    }
     if (col < d.Cout) {
       f32x4 bias = zero4;
       if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
@@ -291,9 +297,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
           *reinterpret_cast<f32x4*>(yb + (size_t)p * d.Cout) = v;
-          const f32x4 dl = v - piv;
-          st1 += dl;
-          st2 += dl * dl;
+          if (d.stats_mode == LVAE_STATS_BN_BWD) {
+            if (d.stats_out) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+                st1[j] += gj;
+                st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
+              }
+            }
+          } else {
+            const f32x4 dl = v - piv;
+            st1 += dl;
+            st2 += dl * dl;
+          }
         }
       }
     }

@@ -388,6 +388,9 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   LVAE_REQUIRE(d->y != nullptr, LVAE_EINVAL, "lvae_conv2d_f32: null y");
   LVAE_REQUIRE(d->stats_out == nullptr || (d->stats_pivot != nullptr && lvae_conv2d_stats_rows(d) > 0), LVAE_EINVAL,
                "lvae_conv2d_f32: stats_out set but lvae_conv2d_stats_rows(d) == 0 (this kernel variant has no statistics epilogue)");
+  LVAE_REQUIRE(d->stats_out == nullptr || d->stats_mode == LVAE_STATS_BN_FWD ||
+                   (d->stats_mode == LVAE_STATS_BN_BWD && d->stats_x != nullptr && (reinterpret_cast<uintptr_t>(d->stats_x) & 15) == 0),
+               LVAE_EINVAL, "lvae_conv2d_f32: bad stats_mode / stats_x");
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
   if (!halo_off) {
     int hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);

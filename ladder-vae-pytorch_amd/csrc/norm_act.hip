@@ -534,6 +534,33 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
   return 0;
 }
 
+extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, const float* dh, const float* x, int64_t M, int32_t C,
+                                             const float* scale, const float* shift, int32_t act, const float* mean,
+                                             const float* rstd, float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n,
+                                             const float* add, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+  LVAE_REQUIRE(parts && rows > 0 && dh && x && dx && M > 0 && C > 0 && scale && shift && mean && rstd && workspace, LVAE_EINVAL,
+               "lvae_affine_act_bwd_parts_f32: bad args");
+  LVAE_REQUIRE(workspace_bytes >= (size_t)2 * C * sizeof(float), LVAE_EWORKSPACE, "lvae_affine_act_bwd_parts_f32: workspace");
+  LVAE_REQUIRE(!drop || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: rows_per_n");
+  LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  float* coef = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, parts, rows, C, M, dgamma, dbeta, coef);
+  LVAE_LAUNCH_CHECK("affine_bwd_finalize");
+  const bool v4 = vec_ok(C, x, dh, dx, add);
+  LVAE_REQUIRE(v4 || C <= 256, LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: C=%d unsupported", C);
+  const RowMap rm2 = row_map(C, v4 ? 4 : 1);
+  const int grid = grid_for(M, rm2.rpp * 4);
+  if (v4)
+    hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale, shift,
+                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+  else
+    hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale, shift,
+                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+  LVAE_LAUNCH_CHECK("affine_bwd_apply");
+  return 0;
+}
+
 extern "C" int lvae_gate_fwd_f32(const float* ab, const float* res, int64_t M, int32_t C, int32_t act, float* out,
                                  void* stream) {
   LVAE_REQUIRE(ab && out && M > 0 && C > 0, LVAE_EINVAL, "lvae_gate_fwd_f32: bad args");

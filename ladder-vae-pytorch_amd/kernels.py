@@ -217,7 +217,30 @@ def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):
     return dab, dx
 
 
-def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
+def bn_coef_block(scale, shift, mean, rstd):
+    """True when the four coefficient vectors are consecutive rows of one buffer (as bn_stats / bn_finalize_parts return them)."""
+    if scale is None or shift is None or mean is None or rstd is None:
+        return False
+    n = 4 * scale.numel()
+    p0 = scale.data_ptr()
+    return shift.data_ptr() == p0 + n and mean.data_ptr() == p0 + 2 * n and rstd.data_ptr() == p0 + 3 * n
+
+
+def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, dbeta, drop=None, add=None):
+    """affine_act_bwd (training-mode BatchNorm) with the reduction already done by the epilogue of the convolution that produced dh
+    (conv2d_dgrad(..., bn_bwd=...))."""
+    Cn = x.shape[-1]
+    M = x.numel() // Cn
+    dx = torch.empty_like(x)
+    ws = workspace(8 * Cn, x.device)
+    rows_per_n = M // x.shape[0]
+    call('lvae_affine_act_bwd_parts_f32', ptr(parts), parts.shape[0], ptr(dh), ptr(x), M, Cn, ptr(scale), ptr(shift), ACT[act],
+         ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(drop), rows_per_n, ptr(add), ptr(dx), ws.data_ptr(), ws.numel(),
+         stream_ptr())
+    return dx
+
+
+def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=None):
     """Gradient w.r.t. the conv input (before any fused input transform). dy NHWC (N,OH,OW,Cout) -> (N,H,W,Cin).
     out_scale (N,Cin) multiplies the result per (sample, channel) (Dropout2d mask of the producer).
     ci_range=(a,b) restricts the result to input channels [a,b) (the two halves of a fused channel concat)."""
@@ -230,8 +253,20 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None):
               GATHER_CONV if g.transposed else GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     d.w = ptr(weight) + 4 * a * g.s_ci
     _conv_ws(d, weight, dy.device)
+    if bn_bwd is None:
+        call('lvae_conv2d_f32', C.byref(d), stream_ptr())
+        return dx
+    # bn_bwd = (x, scale, act): dx is the gradient w.r.t. act(BN(x)); ask the epilogue for the BatchNorm-backward partials
+    # (scale must be the first row of the (4, C) coefficient block, see bn_coef_block). Returns (dx, parts | None).
+    xb, coef, act = bn_bwd
+    parts = None
+    rows = _C.load().lvae_conv2d_stats_rows(C.byref(d))
+    if rows > 0 and out_scale is None and ci_range is None and tuple(xb.shape) == tuple(dx.shape):
+        parts = torch.empty((rows, 2, b - a), dtype=torch.float32, device=dy.device)
+        d.stats_out, d.stats_pivot, d.stats_x = ptr(parts), ptr(coef), ptr(xb)
+        d.stats_mode, d.stats_act = 1, ACT[act]
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
-    return dx
+    return dx, parts
 
 
 def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, in_shift=None, in_act=None):

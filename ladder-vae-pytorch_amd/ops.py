@@ -227,19 +227,35 @@ class ResBlockFn(Function):
         # second half
         w2 = blk.conv2.weight
         wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2, in_act=act)
-        dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
         bn2 = blk.bn2
         train2 = bn2 is not None and ctx.training
-        dy1 = K.affine_act_bwd(dh2, y1, sc2, sh2, act, train2, mean2, rstd2,
-                               grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
+        parts2 = None
+        if train2 and K.bn_coef_block(sc2, sh2, mean2, rstd2):  # BatchNorm-backward sums in the dgrad kernel's epilogue
+            dh2, parts2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw, bn_bwd=(y1, sc2, act))
+        else:
+            dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
+        if parts2 is not None:
+            dy1 = K.affine_act_bwd_parts(parts2, dh2, y1, sc2, sh2, act, mean2, rstd2, grad_buf(bn2.weight), grad_buf(bn2.bias),
+                                         drop=m1)
+        else:
+            dy1 = K.affine_act_bwd(dh2, y1, sc2, sh2, act, train2, mean2, rstd2,
+                                   grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
         # first half
         w1 = blk.conv1.weight
         wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
-        dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
         bn1 = blk.bn1
         train1 = bn1 is not None and ctx.training
-        dx = K.affine_act_bwd(dh1, x, sc1, sh1, act, train1, mean1, rstd1,
-                              grad_buf(bn1.weight) if train1 else None, grad_buf(bn1.bias) if train1 else None, add=dout)
+        parts1 = None
+        if train1 and K.bn_coef_block(sc1, sh1, mean1, rstd1):
+            dh1, parts1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw, bn_bwd=(x, sc1, act))
+        else:
+            dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
+        if parts1 is not None:
+            dx = K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias),
+                                        add=dout)
+        else:
+            dx = K.affine_act_bwd(dh1, x, sc1, sh1, act, train1, mean1, rstd1,
+                                  grad_buf(bn1.weight) if train1 else None, grad_buf(bn1.bias) if train1 else None, add=dout)
         return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 

@@ -375,6 +375,31 @@ def test_bn_statistics_from_gate_epilogue(K, shape):
     torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 64, 32, 8, 8)])
+def test_bn_backward_sums_from_dgrad_epilogue(K, case):
+    """conv2d_dgrad(..., bn_bwd) + affine_act_bwd_parts == conv2d_dgrad followed by affine_act_bwd (Winograd and tile kernels)."""
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(46)
+    xb = nhwc(torch.randn(N, Ci, H, W, generator=g) * 2 + 1)
+    dy = nhwc(torch.randn(N, Co, H, W, generator=g))
+    wp = packed_weight(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).cuda(), torch.randn(Ci, generator=g).cuda()
+    sc, sh, mean, rstd = K.bn_stats(xb, gamma, beta, None, None)
+    assert K.bn_coef_block(sc, sh, mean, rstd)
+    drop = ((torch.rand(N, Ci, generator=g) < 0.8).float() / 0.8).cuda()
+    add = nhwc(torch.randn(N, Ci, H, W, generator=g))
+    geom = K.ConvGeom(wp, 1, 1)
+    dh, parts = K.conv2d_dgrad(dy, wp, geom, (H, W), bn_bwd=(xb, sc, 'elu'))
+    assert parts is not None, "this shape is meant to take a kernel with the statistics epilogue"
+    assert torch.equal(dh, K.conv2d_dgrad(dy, wp, geom, (H, W)))
+    dg, db = torch.zeros(Ci, device='cuda'), torch.zeros(Ci, device='cuda')
+    dg2, db2 = torch.zeros(Ci, device='cuda'), torch.zeros(Ci, device='cuda')
+    got = K.affine_act_bwd_parts(parts, dh, xb, sc, sh, 'elu', mean, rstd, dg, db, drop=drop, add=add)
+    ref = K.affine_act_bwd(dh, xb, sc, sh, 'elu', True, mean, rstd, dg2, db2, drop=drop, add=add)
+    assert rel(got, ref) < 2e-6
+    assert rel(dg, dg2) < 1e-5 and rel(db, db2) < 1e-5
+
+
 def test_gate(K):
     g = torch.Generator().manual_seed(6)
     ab = torch.randn(5, 128, 4, 4, generator=g, requires_grad=True)
