@@ -82,13 +82,14 @@ class TrainStep:
         fused = self.allreduce is None or (self.allreduce.world == 1 and not getattr(self.allreduce, 'force', False))
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures
+        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
             self.static_out = self._fwd_bwd(self.static_x)
             if fused:
                 self.opt.step()
         if not fused:
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
                 self.opt.step()
         self._bns = self.model.bn_modules()
 
