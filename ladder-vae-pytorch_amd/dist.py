@@ -62,7 +62,7 @@ class GradAllReduce:
 
     def run(self):
         """Reduce all buckets; the caller's current stream waits for completion (no host sync)."""
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or os.environ.get('LVAE_SKIP_ALLREDUCE') == '1':  # second: profiling only
             return
         if not self.on_gpu:
             for lo, hi in self.buckets:
