@@ -110,9 +110,6 @@ class LVAEExperiment:
         args.batch_norm = not args.no_batch_norm
         if args.likelihood is None:
             args.likelihood = DATASETS[args.dataset_name][2]
-        if args.simple_data_dependent_init:
-            raise NotImplementedError("--data-dep-init relies on boilr.nn.init.data_dependent_init, which is absent "
-                                      "(SURVEY.md §8f rank 3)")
         return args
 
     @staticmethod

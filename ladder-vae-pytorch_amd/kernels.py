@@ -146,11 +146,42 @@ def _conv_ws(d, weight, device):
         prepared.attach(d, weight, device, need)
 
 
+_ddi = None  # set by init.data_dependent_init for the duration of its forward pass
+
+
+def _ddi_conv(state, x, weight, g, bias, x2, in_scale, in_shift, in_act, out_scale, out_act):
+    """One convolution of the data-dependent initialisation pass (init.py): plain output, per-channel statistics, parameter
+    rescale in place, corrected output, then the caller's epilogue."""
+    global _ddi
+    _ddi = None
+    try:
+        y = conv2d(x, weight, g, bias=bias, x2=x2, in_scale=in_scale, in_shift=in_shift, in_act=in_act)
+        _, _, mean, rstd = bn_stats(y, None, None, None, None, eps=1e-20)
+    finally:
+        _ddi = state
+    scale = 1.0 / (1.0 / rstd + 1e-5)
+    weight.mul_(scale.view(1, -1, 1, 1) if g.transposed else scale.view(-1, 1, 1, 1))
+    if bias is not None:
+        bias.sub_(mean).mul_(scale)
+        y = affine_act(y, scale, -mean * scale, None)
+    else:
+        y = affine_act(y, scale, torch.zeros_like(scale), None)
+    if out_scale is not None or out_act is not None:
+        ones, zeros = torch.ones_like(scale), torch.zeros_like(scale)
+        y = affine_act(y, ones, zeros, out_act, row_scale=out_scale)
+    state['done'].add(weight.data_ptr())
+    state['count'] += 1
+    return y
+
+
 def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None,
            stats_pivot=None):
     """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC.
     stats_pivot (Cout,): also ask the kernel's epilogue for BatchNorm partials of y around that pivot; returns (y, parts) with
     parts (rows, 2, Cout) for bn_finalize_parts, or (y, None) when the kernel variant chosen for this shape has no such epilogue."""
+    if _ddi is not None and weight.data_ptr() not in _ddi['done']:
+        y = _ddi_conv(_ddi, x, weight, g, bias, x2, in_scale, in_shift, in_act, out_scale, out_act)
+        return y if stats_pivot is None else (y, None)
     _chk_nhwc(x, 'x')
     N, H, W, C1 = x.shape
     if x2 is not None:
@@ -183,7 +214,7 @@ def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True, stats_pivot=None):
     Cn = g.Cout // 2
     fused_ok = (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cin <= 128 and
                 g.Cout <= 128 and g.Cin % 4 == 0 and g.Cout % 8 == 0 and (g.s_co == 1 or g.s_ci == 1))
-    if not fused_ok:
+    if not fused_ok or (_ddi is not None and weight.data_ptr() not in _ddi['done']):
         ab = conv2d(x, weight, g, bias=bias)
         out = gate_fwd(ab, res, act)
         return (ab, out) if stats_pivot is None else (ab, out, None)

@@ -34,6 +34,17 @@ def main(argv=None):
         load_checkpoint(args.resume, model, opt)
     model.train()
     arena = model.pack()
+    per_rank = args.batch_size // max(1, world)
+    data = None
+    if args.data_npz:
+        data = torch.from_numpy(np.load(args.data_npz)['data']).float()
+    if args.simple_data_dependent_init and not args.resume:
+        # experiment_manager.py:61-72: the first batch_size training images (parity unpinned, see init.py)
+        from .init import data_dependent_init
+        x0 = data[:args.batch_size] if data is not None else synthetic_batch(exp, args.batch_size, torch.Generator().manual_seed(args.seed))
+        n = data_dependent_init(model, x0.to(exp.device))
+        if rank == 0:
+            print('data-dependent init: %d convolutions rescaled' % n)
     ldist.broadcast_flat(arena.params)
     allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
     step_fn = TrainStep(model, opt, beta=1.0, use_graph=not args.no_graph and args.beta_anneal == 0, allreduce=allreduce)
@@ -44,9 +55,6 @@ def main(argv=None):
     if args.batch_size % world:
         raise SystemExit('--batch-size must be divisible by the world size')
     per_rank = args.batch_size // world
-    data = None
-    if args.data_npz:
-        data = torch.from_numpy(np.load(args.data_npz)['data']).float()
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     steps = args.steps or args.max_steps
     t0, seen = time.time(), 0

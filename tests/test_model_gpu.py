@@ -292,3 +292,35 @@ def test_large_batch_step_through_winograd_paths_matches_oracle():
     K.prepared.entries.clear()
     K.prepared.table = None
 
+
+def test_data_dependent_init_is_a_fixed_point_after_one_pass():
+    """--data-dep-init (parity unpinned: boilr is absent): after one pass every convolution's output on the init batch has zero
+    mean / unit std per channel, so a second pass over the same batch with the same noise must leave the parameters where they
+    are, while the first pass must have moved them."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd.init import data_dependent_init
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import PhiloxNoise
+    cfg = dict(color_ch=3, z_dims=[8, 8], blocks_per_layer=1, downsample=[1, 1], nonlin='elu', merge_type='residual',
+               batchnorm=True, stochastic_skip=True, n_filters=16, dropout=0.0, free_bits=0.5, learn_top_prior=True,
+               img_shape=(32, 32), likelihood_form='discr_log_mix', res_block_type='bacdbacd', gated=True,
+               no_initial_downscaling=False, analytical_kl=False)
+    torch.manual_seed(5)
+    model = LadderVAE(**cfg).cuda()
+    model.pack()
+    x = (torch.floor(256 * torch.rand(32, 3, 32, 32)) / 255).cuda()
+    convs = {k: v for k, v in model.named_parameters() if v.dim() == 4 and k.endswith('.weight')}
+    before = {k: v.detach().clone() for k, v in convs.items()}
+    model.noise = PhiloxNoise(seed=9)
+    n = data_dependent_init(model, x)
+    assert n >= len(convs) - 1 and n > 10
+    after1 = {k: v.detach().clone() for k, v in convs.items()}
+    moved = sum(float((after1[k] - before[k]).norm() / before[k].norm()) > 1e-3 for k in convs)
+    assert moved >= len(convs) // 2
+    model.noise = PhiloxNoise(seed=9)
+    data_dependent_init(model, x)
+    for k, v in convs.items():
+        assert float((v.detach() - after1[k]).norm() / after1[k].norm()) < 2e-3, k
+    out = model(x)                           # the product path still runs after the in-place updates
+    assert torch.isfinite(out['ll']).all()
+
