@@ -25,8 +25,13 @@ def main(argv=None):
         torch.cuda.set_device(local)
     exp = LVAEExperiment(argv=argv)
     args = exp.args
+    loader = None
     if not (args.synthetic or args.data_npz):
-        raise SystemExit("datasets cannot be downloaded here: pass --synthetic or --data-npz FILE")
+        from .data import DatasetLoader  # the reference's on-disk formats (experiment/data.py); nothing is downloaded here
+        try:
+            loader = DatasetLoader(args)
+        except RuntimeError as e:
+            raise SystemExit("%s\n(or pass --synthetic / --data-npz FILE)" % e)
     model, opt = exp.model, exp.optimizer
     model.noise.seed ^= rank * 0x9E3779B9
     if args.resume:
@@ -41,7 +46,7 @@ def main(argv=None):
     if args.simple_data_dependent_init and not args.resume:
         # experiment_manager.py:61-72: the first batch_size training images (parity unpinned, see init.py)
         from .init import data_dependent_init
-        x0 = data[:args.batch_size] if data is not None else synthetic_batch(exp, args.batch_size, torch.Generator().manual_seed(args.seed))
+        x0 = loader.train.dataset.tensors[0][:args.batch_size] if loader is not None else data[:args.batch_size] if data is not None else synthetic_batch(exp, args.batch_size, torch.Generator().manual_seed(args.seed))
         n = data_dependent_init(model, x0.to(exp.device))
         if rank == 0:
             print('data-dependent init: %d convolutions rescaled' % n)
@@ -57,9 +62,20 @@ def main(argv=None):
     per_rank = args.batch_size // world
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     steps = args.steps or args.max_steps
+    batches = None
     t0, seen = time.time(), 0
     for step in range(1, steps + 1):
-        if data is not None:
+        if loader is not None:
+            if step == 1 or batches is None:
+                batches = iter(loader.train)
+            try:
+                xb = next(batches)[0]
+            except StopIteration:                      # next epoch: reshuffled by the DataLoader
+                batches = iter(loader.train)
+                xb = next(batches)[0]
+            lo, hi = ldist.shard_batch(args.batch_size, rank, world)
+            x = xb[lo:hi]
+        elif data is not None:
             idx = torch.randint(0, data.shape[0], (args.batch_size,), generator=torch.Generator().manual_seed(args.seed + step))
             lo, hi = ldist.shard_batch(args.batch_size, rank, world)
             x = data[idx[lo:hi]]

@@ -74,3 +74,48 @@ def test_noise_tape_layout_conversion():
     assert torch.equal(e, eps.permute(0, 2, 3, 1)) and t.exhausted()
     with pytest.raises(RuntimeError):
         t.normal((1, 1, 1, 1), torch.device('cpu'))
+
+
+def test_data_pipeline_formats(tmp_path):
+    """experiment/data.py + lib/datasets.py on synthetic files: .amat -> npz conversion, train = train + valid, NaN labels,
+    CIFAR10 pickle batches as ToTensor floats, loader shapes (shuffled / drop_last train, ordered test)."""
+    import pickle
+    import types
+    import numpy as np
+    import torch
+    import lvae_amd  # noqa: F401
+    from lvae_amd import data as D
+    rng = np.random.default_rng(0)
+    folder = tmp_path / 'static_bin_mnist'
+    folder.mkdir()
+    raw = {}
+    for split, n in (('train', 50), ('valid', 10), ('test', 20)):
+        raw[split] = (rng.random((n, 784)) > 0.5).astype(int)
+        with open(folder / ('binarized_mnist_%s.amat' % split), 'w') as f:
+            for row in raw[split]:
+                f.write(' '.join(str(v) for v in row) + '\n')
+    tr = D.StaticBinaryMnist(str(folder), train=True)
+    te = D.StaticBinaryMnist(str(folder), train=False)
+    assert (folder / 'binarized_mnist_train.npz').exists()            # converted next to the .amat
+    assert tuple(tr.tensors[0].shape) == (60, 1, 28, 28) and tr.tensors[0].dtype == torch.float32
+    np.testing.assert_array_equal(tr.tensors[0].numpy().reshape(60, 784), np.concatenate([raw['train'], raw['valid']]).astype(np.float32))
+    np.testing.assert_array_equal(te.tensors[0].numpy().reshape(20, 784), raw['test'].astype(np.float32))
+    assert torch.isnan(tr.tensors[1]).all()
+    args = types.SimpleNamespace(dataset_name='static_mnist', batch_size=16, test_batch_size=7)
+    dl = D.DatasetLoader(args, folder=str(folder))
+    assert len(dl.train) == 3 and len(dl.test) == 3                     # 60 // 16 (drop_last), ceil(20 / 7)
+    assert tuple(dl.data_shape) == (1, 28, 28) and dl.color_ch == 1 and tuple(dl.img_size) == (28, 28)
+    assert sorted(dl.train.dataset.tensors[0].sum((1, 2, 3)).tolist()) == sorted(tr.tensors[0].sum((1, 2, 3)).tolist())  # shuffled copy
+    cdir = tmp_path / 'cifar10' / 'cifar-10-batches-py'
+    cdir.mkdir(parents=True)
+    imgs = {}
+    for name in ['data_batch_%d' % i for i in range(1, 6)] + ['test_batch']:
+        imgs[name] = rng.integers(0, 256, (4, 3072), dtype=np.uint8)
+        with open(cdir / name, 'wb') as f:
+            pickle.dump({'data': imgs[name], 'labels': [1, 2, 3, 4]}, f)
+    args = types.SimpleNamespace(dataset_name='cifar10', batch_size=8, test_batch_size=3)
+    dl = D.DatasetLoader(args, folder=str(tmp_path / 'cifar10'))
+    x = dl.test.dataset.tensors[0]
+    assert tuple(x.shape) == (4, 3, 32, 32) and float(x.max()) <= 1.0
+    np.testing.assert_allclose(x.numpy().reshape(4, 3072), imgs['test_batch'].astype(np.float32) / 255.0)
+    assert len(dl.train.dataset) == 20 and dl.color_ch == 3
