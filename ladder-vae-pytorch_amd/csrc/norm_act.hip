@@ -312,6 +312,76 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
   }
 }
 
+// Low-resolution levels: few partial rows (<= 128) and few apply workgroups, so every workgroup sums the partials itself (a few
+// KB out of L2) instead of waiting for a separate finalize launch; workgroup 0 also accumulates dgamma / dbeta. C % 4 == 0,
+// C <= 256; the summation order is the same in every workgroup (bitwise identical coefficients).
+__global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float* __restrict__ parts, int rows, const float* __restrict__ dh,
+                                                                     const float* __restrict__ x, int M, int C, int cols, int rpp,
+                                                                     const float* scale, const float* shift, int act,
+                                                                     const float* mean, const float* rstd, float* dgamma,
+                                                                     float* dbeta, const float* drop, int rows_per_n,
+                                                                     const float* __restrict__ add, float* __restrict__ dx) {
+  __shared__ float red[2][256 * 4];
+  __shared__ float cf[2][256];
+  const int t = threadIdx.x, col = t % cols, rg = t / cols;
+  const int c = col * 4;
+  {
+    // slice rg of the partial rows for channel group col: rows rg, rg + nsl, ... (nsl = 256 / cols slices)
+    const int nsl = 256 / cols;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (rg < nsl)
+      for (int r = rg; r < rows; r += nsl) {
+        a += *reinterpret_cast<const f32x4*>(parts + (size_t)r * 2 * C + c);
+        b += *reinterpret_cast<const f32x4*>(parts + (size_t)r * 2 * C + C + c);
+      }
+    *reinterpret_cast<f32x4*>(&red[0][t * 4]) = a;
+    *reinterpret_cast<f32x4*>(&red[1][t * 4]) = b;
+    __syncthreads();
+    if (t < C) {
+      const int cg = t >> 2, j = t & 3;
+      double sa = 0.0, sb = 0.0;
+      for (int sl = 0; sl < nsl; ++sl) {
+        sa += (double)red[0][(sl * cols + cg) * 4 + j];
+        sb += (double)red[1][(sl * cols + cg) * 4 + j];
+      }
+      cf[0][t] = (float)(sa / (double)M);
+      cf[1][t] = (float)(sb / (double)M);
+      if (blockIdx.x == 0) {
+        if (dbeta) dbeta[t] += (float)sa;
+        if (dgamma) dgamma[t] += (float)sb;
+      }
+    }
+    __syncthreads();
+  }
+  if (rg >= rpp) return;
+  float sc[4], sh[4], mu[4], rs[4], c1[4], c2[4];
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = scale[c + j];
+    sh[j] = shift[c + j];
+    mu[j] = mean[c + j];
+    rs[j] = rstd[c + j];
+    c1[j] = cf[0][c + j];
+    c2[j] = cf[1][c + j];
+  }
+  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
+    const size_t off = (size_t)row * C + c;
+    F4 xv = Vec<4>::load(x + off);
+    F4 gv = Vec<4>::load(dh + off);
+    F4 av;
+    if (add) av = Vec<4>::load(add + off);
+    const float* dr = drop ? drop + (size_t)(row / rows_per_n) * C + c : nullptr;
+    for (int j = 0; j < 4; ++j) {
+      const float xx = xv.v[j];
+      float g = gv.v[j] * act_grad(xx * sc[j] + sh[j], act);
+      g = (g - c1[j] - (xx - mu[j]) * rs[j] * c2[j]) * sc[j];
+      if (dr) g *= dr[j];
+      if (add) g += av.v[j];
+      gv.v[j] = g;
+    }
+    Vec<4>::store(dx + off, gv);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // gate
 // ---------------------------------------------------------------------------------------------------------
@@ -544,6 +614,14 @@ extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, c
   LVAE_REQUIRE(!drop || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: rows_per_n");
   LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: too many rows");
   hipStream_t s = (hipStream_t)stream;
+  if (rows <= 128 && vec_ok(C, x, dh, dx, add) && vec_ok(C, parts, drop) && 256 % (C / 4) == 0) {
+    const RowMap rm = row_map(C, 4);
+    const int grid = grid_for(M, rm.rpp * 4);
+    hipLaunchKernelGGL(affine_bwd_apply_parts_kernel, dim3(grid), dim3(256), 0, s, parts, rows, dh, x, (int)M, C, rm.cols, rm.rpp, scale,
+                       shift, act, mean, rstd, dgamma, dbeta, drop, (int)rows_per_n, add, dx);
+    LVAE_LAUNCH_CHECK("affine_bwd_apply_parts");
+    return 0;
+  }
   float* coef = static_cast<float*>(workspace);
   hipLaunchKernelGGL(affine_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, parts, rows, C, M, dgamma, dbeta, coef);
   LVAE_LAUNCH_CHECK("affine_bwd_finalize");
