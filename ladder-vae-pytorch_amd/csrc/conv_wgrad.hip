@@ -575,7 +575,8 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     const bool groupable = !halo_off && !wino && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
                            conv1x1_wgrad_workspace(&descs[i]) == 0;
     // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
-    kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < 65536 ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
+    static const int64_t wino_group_max = getenv("LVAE_WINO_GROUP_MAX_M") ? atoll(getenv("LVAE_WINO_GROUP_MAX_M")) : 65536;  // tuning switch
+    kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < wino_group_max ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
                    : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1);
   }
   std::vector<char> done(n, 0);
