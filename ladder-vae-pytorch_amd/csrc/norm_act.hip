@@ -113,24 +113,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* scale, float* shift, float* mean_out, float* rstd_out) {
   __shared__ double part[4][2];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double a = 0.0, b = 0.0;
+  // per-thread and in-wave sums in fp32 (at most chunks/256 + 6 additions per value, fixed order), doubles from there on
+  float af = 0.f, bf = 0.f;
   for (int k = tid; k < chunks; k += 256) {
-    a += ws[(size_t)k * 2 * C + c];
-    b += ws[(size_t)k * 2 * C + C + c];
+    af += ws[(size_t)k * 2 * C + c];
+    bf += ws[(size_t)k * 2 * C + C + c];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    a += shfl_xor_d(a, o);
-    b += shfl_xor_d(b, o);
+    af += __shfl_xor(af, o, 64);
+    bf += __shfl_xor(bf, o, 64);
   }
   if (lane == 0) {
-    part[wv][0] = a;
-    part[wv][1] = b;
+    part[wv][0] = (double)af;
+    part[wv][1] = (double)bf;
   }
   __syncthreads();
   if (tid != 0) return;
-  a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-  b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+  double a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+  double b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
   const double inv_m = 1.0 / (double)M, dm = a * inv_m;  // mean - pivot
   double m2 = b - a * dm;                                 // sum (x - mean)^2
   if (m2 < 0.0) m2 = 0.0;
@@ -250,24 +251,24 @@ __global__ __launch_bounds__(256) void affine_bwd_finalize_kernel(const float* _
                                                                   float* dgamma, float* dbeta, float* coef) {
   __shared__ double part[4][2];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double a = 0.0, b = 0.0;
+  float af = 0.f, bf = 0.f;
   for (int k = tid; k < chunks; k += 256) {
-    a += ws[(size_t)k * 2 * C + c];
-    b += ws[(size_t)k * 2 * C + C + c];
+    af += ws[(size_t)k * 2 * C + c];
+    bf += ws[(size_t)k * 2 * C + C + c];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    a += shfl_xor_d(a, o);
-    b += shfl_xor_d(b, o);
+    af += __shfl_xor(af, o, 64);
+    bf += __shfl_xor(bf, o, 64);
   }
   if (lane == 0) {
-    part[wv][0] = a;
-    part[wv][1] = b;
+    part[wv][0] = (double)af;
+    part[wv][1] = (double)bf;
   }
   __syncthreads();
   if (tid != 0) return;
-  a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-  b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+  const double a = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+  const double b = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   coef[c] = (float)(a / (double)M);
