@@ -9,7 +9,6 @@ the absent boilr.eval.BaseOfflineEvaluator / VAEExperimentManager.test_procedure
 
 CLI: python -m lvae_amd.evaluate --synthetic --ll --ll-samples 100 --ps  <model flags of main.py>
 """
-import math
 
 import numpy as np
 import torch

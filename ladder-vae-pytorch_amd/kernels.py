@@ -87,8 +87,6 @@ class _PreparedWeights:
         self.entries = {}   # key -> dict(weight, U, desc bytes, stamp)
         self.epoch = 0
         self.table = None   # device table of the entries, rebuilt when the set changes
-        self.table_keys = None
-        self.max_cout = 0
         self.enabled = True
 
     def stamp(self, weight):
