@@ -114,10 +114,20 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
 
 constexpr int WLDO = 68;  // R row stride (floats)
 
-template <int CIN>  // reduction channels padded to 64 or 128 (the DMoL head's dgrad reduces over 100)
+// CIN: reduction channels padded to 64 or 128 (the DMoL head's dgrad reduces over 100).
+// NH: 32-wide output-channel blocks per workgroup. 2 = the layout described above. 1 (64 channels split over two workgroups) is
+// for layers with fewer than 256 pixel tiles (the 8x8 level at batch 256): it fills all CUs, halves the dependent MFMA chain
+// of a wave, and — one wave per SIMD, nothing else to hide an L2 round trip — keeps its U fragments three k-steps ahead in a
+// register ring pinned with sched_barrier.
+template <int CIN, int NH>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   constexpr int WLDA = CIN + 4;     // halo pixel stride (floats)
   constexpr int KSTEPS = CIN / 8, NSLICE = CIN / 16;
+  constexpr int CW = 32 * NH;       // output channels of this workgroup
+  constexpr int C4N = CW / 4;       // float4 per output pixel
+  constexpr int PG = 256 / C4N;     // pixel groups of the store pass
+  constexpr int QN = 128 / PG;      // store passes
+  constexpr int RING = NH == 1 ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;  // [halo_px][WLDA]; reused as R[4][2][32][WLDO] by the epilogue
   const lvae_conv_desc& d = a.d;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int tile_n = bid % a.ntn;
   const int tm = bid / a.ntn;
   const int th_idx = tm % a.tiles_h, ig = tm / a.tiles_h;
-  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
+  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * CW;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- halo patch in four 16-channel slices; slot = (pixel, float4 within the slice)
@@ -198,20 +208,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const size_t slab = (size_t)a.Npad * CIN;
   const float* ub = a.U + (size_t)(4 * wave) * slab + ((size_t)lh * a.Npad + co0 + li) * 4;
   const size_t kstep = (size_t)2 * a.Npad * 4;
-  f32x4 bf[2][4][2];
+  f32x4 bf[RING][4][NH];
   auto load_u = [&](int ks, int buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) bf[buf][j][h] = *reinterpret_cast<const f32x4*>(ub + j * slab + ks * kstep + h * 128);
+      for (int h = 0; h < NH; ++h) bf[buf][j][h] = *reinterpret_cast<const f32x4*>(ub + j * slab + ks * kstep + h * 128);
   };
-  load_u(0, 0);
+#pragma unroll
+  for (int q = 0; q < RING - 1; ++q) load_u(q, q);
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NH];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.f;
 
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    if (ks + 1 < KSTEPS) load_u(ks + 1, (ks + 1) & 1);
+    if (ks + RING - 1 < KSTEPS) load_u(ks + RING - 1, (ks + RING - 1) % RING);
+    if (NH == 1) __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead: the scheduler otherwise sinks it next to its use
     f32x4 tt[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -237,10 +249,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks & 1][j][h][e], acc[j][h], 0, 0, 0);
+          acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks % RING][j][h][e], acc[j][h], 0, 0, 0);
+    if (NH == 1) __builtin_amdgcn_sched_barrier(0);
     if ((ks & 1) && ks < KSTEPS - 1) {  // publish the next 16-channel slice, start fetching the one after
       const int c = (ks + 1) >> 1;
       store_slice(c);
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   // ---- R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]; accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh
   float* Rs = smem;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
   __syncthreads();
   {
-    const int c4 = (t & 15) * 4, col = co0 + c4;
+    const int c4 = (t % C4N) * 4, col = co0 + c4;
     f32x4 st1 = zero4, st2 = zero4, piv = zero4;  // BatchNorm partials of the stored values (d.stats_out)
     if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
     f32x4 bsh = piv, bmu = piv, brs = piv;  // LVAE_STATS_BN_BWD: piv = scale, then shift, mean, rstd of the [4][Cout] block
@@ -281,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       const int nvalid = min(a.NI, d.N - n0) * thw;
       float* yb = d.y + ((size_t)(n0 * d.H + oh0) * d.W) * d.Cout + col;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int p = (t >> 4) + 16 * q;
+      for (int q = 0; q < QN; ++q) {
+        const int p = t / C4N + PG * q;
         if (p < nvalid) {
           const int img = fastdiv(p, a.m_thw), pr = p - img * thw;
           const int oy = fastdiv(pr, a.m_tw), ox = pr - oy * a.TW;
@@ -315,17 +328,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         }
       }
     }
-    if (d.stats_out) {  // 16 pixel groups x 64 channels -> one row of partials per pixel tile (fixed order)
+    if (d.stats_out) {  // PG pixel groups x CW channels -> one row of partials per pixel tile (fixed order)
       __syncthreads();  // R is dead
       float* red = smem;
-      *reinterpret_cast<f32x4*>(red + (t >> 4) * 64 + c4) = st1;
-      *reinterpret_cast<f32x4*>(red + 1024 + (t >> 4) * 64 + c4) = st2;
+      *reinterpret_cast<f32x4*>(red + (t / C4N) * CW + c4) = st1;
+      *reinterpret_cast<f32x4*>(red + PG * CW + (t / C4N) * CW + c4) = st2;
       __syncthreads();
-      if (t < 128) {
-        const int c = t & 63, which = t >> 6;
+      if (t < 2 * CW) {
+        const int c = t % CW, which = t / CW;
         float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v += red[which * 1024 + r * 64 + c];
+        for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
         if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
       }
     }
@@ -335,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 static bool al16w2(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int wino_kpad(const lvae_conv_desc* d) { return d->C1 <= 64 ? 64 : 128; }
+static bool kpad_is64(const lvae_conv_desc* d) { return d->C1 <= 64; }
 
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d) {
   const int ntn = (d->Cout + 63) / 64;
@@ -349,7 +363,7 @@ bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
   if (Cin < 36 || Cin > 128 || Cin % 4 != 0 || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->W > 128) return false;
   if (!al16w2(d->x) || !al16w2(d->y) || !al16w2(d->bias) || !al16w2(d->in_scale) || !al16w2(d->in_shift) || !al16w2(d->out_scale)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 192;  // tuning switch
+  static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 64;  // tuning switch
   if (M < min_m || M * 128 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
   return true;
 }
@@ -395,8 +409,10 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.tiles_x = d->W / 2;
   a.wt_per_img = (TH / 2) * a.tiles_x;
   a.n_wt = NI * a.wt_per_img;
-  a.ntn = (d->Cout + 63) / 64;
-  a.Npad = a.ntn * 64;
+  a.Npad = (d->Cout + 63) / 64 * 64;
+  const int img_groups_ = (d->N + NI - 1) / NI;
+  const bool narrow = kpad_is64(d) && img_groups_ * a.tiles_h < 256;  // fewer pixel tiles than CUs: 32-channel workgroups
+  a.ntn = narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64;
   a.m_thw = fastdiv_magic(TH * d->W);
   a.m_tw = fastdiv_magic(d->W);
   a.m_per_img = fastdiv_magic(a.halo_h * a.halo_w);
@@ -411,8 +427,9 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   if (lds > 160 * 1024) return -1000;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -429,8 +446,9 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (kpad == 64) hipLaunchKernelGGL(conv3x3_wino_kernel<64>, grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(conv3x3_wino_kernel<128>, grid, dim3(256), lds, s, a);
+  if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1>), grid, dim3(256), lds, s, a);
+  else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2>), grid, dim3(256), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wino");
   return 0;
 }

@@ -102,6 +102,9 @@ WINO_CASES = [
     (193, 100, 16, 16),  # two output-channel tiles, the second ragged
     (260, 32, 24, 8),    # 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
     (97, 128, 32, 16),   # four 32-channel blocks in the weight-gradient kernel, ranges of unequal length
+    (64, 64, 16, 16),    # fewer than 256 pixel tiles: the 32-channel-per-workgroup variant with the pinned weight ring
+    (257, 100, 8, 8),    # ... ragged last channel block, two images per tile, ragged last tile
+    (300, 32, 8, 8),     # ... a single channel block
 ]
 
 
@@ -329,7 +332,8 @@ def test_colsum(K, shape):
     torch.testing.assert_close(out.cpu(), x.sum(0), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 32, 64, 8, 8), (9, 64, 100, 32, 32)])
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 32, 64, 8, 8), (9, 64, 100, 32, 32),
+                                  (66, 64, 64, 16, 16), (259, 64, 100, 8, 8)])   # last two: 32-channel Winograd workgroups
 def test_bn_statistics_from_conv_epilogue(K, case):
     """conv2d(..., stats_pivot) + bn_finalize_parts == conv2d followed by bn_stats on its output (Winograd and tile kernels)."""
     N, Ci, Co, H, W = case
@@ -375,7 +379,7 @@ def test_bn_statistics_from_gate_epilogue(K, shape):
     torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 64, 32, 8, 8)])
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 64, 32, 8, 8), (66, 64, 64, 16, 16), (259, 64, 64, 8, 8)])
 def test_bn_backward_sums_from_dgrad_epilogue(K, case):
     """conv2d_dgrad(..., bn_bwd) + affine_act_bwd_parts == conv2d_dgrad followed by affine_act_bwd (Winograd and tile kernels)."""
     N, Ci, Co, H, W = case
