@@ -411,7 +411,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.n_wt = NI * a.wt_per_img;
   a.Npad = (d->Cout + 63) / 64 * 64;
   const int img_groups_ = (d->N + NI - 1) / NI;
-  const bool narrow = kpad_is64(d) && img_groups_ * a.tiles_h < 256;  // fewer pixel tiles than CUs: 32-channel workgroups
+  static const int narrow_tiles = getenv("LVAE_WINO_NARROW_TILES") ? atoi(getenv("LVAE_WINO_NARROW_TILES")) : 256;  // tuning switch
+  const bool narrow = kpad_is64(d) && img_groups_ * a.tiles_h < narrow_tiles;  // fewer pixel tiles than CUs: 32-channel workgroups
   a.ntn = narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64;
   a.m_thw = fastdiv_magic(TH * d->W);
   a.m_tw = fastdiv_magic(d->W);
