@@ -79,7 +79,9 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): |abs err| < 2e-7 on a value in (0, 1); the IEEE expf + division it replaces cost ~25
+// instructions per element in the gate kernels
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // numerically stable softplus, threshold 20 like torch
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
