@@ -12,7 +12,16 @@
  *    default stream. `stream` is a hipStream_t passed as void*.
  *  - every function returns 0 on success, a negative LVAE_E* code for a rejected argument, or the positive
  *    hipError_t of a failed launch. `lvae_last_error()` returns a static description of the last failure.
- *  - re-entrant; no mutable global state except the last-error string (thread-local).
+ *  - re-entrant. Mutable process state: the thread-local last-error string, and one atomic "dynamic-LDS attribute set" flag per
+ *    kernel (an idempotent hipFuncSetAttribute on first use). Read-only process state: the tuning / A-B switches below, each read
+ *    from the environment once on first use; every value selects among kernel variants that pass the same parity tests:
+ *      LVAE_DISABLE_WINO, LVAE_DISABLE_WINO_WGRAD, LVAE_DISABLE_HALO, LVAE_DISABLE_W1X1   (fall back to the direct kernels)
+ *      LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
+ *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
+ *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
+ *    caller owns (ladder-vae-pytorch_amd/dist.py). SURVEY.md §8(b) sketched lvae_allreduce_{init,enqueue,wait,destroy}; they
+ *    would only re-wrap ncclAllReduce on a side stream, which torch.distributed already is on this platform, so the boundary
+ *    stops at "gradients complete in one flat device buffer" (lvae_adamax_step_f32 takes the 1/world scale).
  */
 #ifndef LVAE_HIP_H
 #define LVAE_HIP_H
@@ -24,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 4
+#define LVAE_ABI_VERSION 5
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -224,6 +233,16 @@ int lvae_normal_stochastic_bwd_f32(const float* p, int32_t p_bcast, const float*
                                    const float* dz, const float* g_lp, const float* g_lq, const float* g_kl,
                                    const float* g_ks, int32_t N, int32_t HW, int32_t Z, int32_t mode,
                                    int32_t analytical_kl, float* dp, float* dq, void* stream);
+
+/* `kl_elementwise` of NormalStochasticBlock2d.forward (lib/stochastic.py:88-91,108) and kl_normal_mc (lib/stochastic.py:209-226):
+ * out[n,pix,c] = log q(z) - log p(z)  (analytical_kl = 0)  or  KL(q || p)  (analytical_kl = 1).  p, q [N|1,HW,2Z] (mu | logvar on
+ * the channel axis; *_bcast = 1: one row set shared by the batch), z, out [N,HW,Z]. The backward writes dp, dq [N,HW,2Z] (the
+ * caller sums a broadcast operand over N) and, when dz != NULL, dz [N,HW,Z] (zero for the analytical form). */
+int lvae_kl_elementwise_fwd_f32(const float* p, int32_t p_bcast, const float* q, int32_t q_bcast, const float* z, int32_t N,
+                                int32_t HW, int32_t Z, int32_t analytical_kl, float* out, void* stream);
+int lvae_kl_elementwise_bwd_f32(const float* p, int32_t p_bcast, const float* q, int32_t q_bcast, const float* z, const float* g,
+                                int32_t N, int32_t HW, int32_t Z, int32_t analytical_kl, float* dp, float* dq, float* dz,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Likelihood heads (elementwise part; the 3x3 parameter conv is lvae_conv2d_f32)

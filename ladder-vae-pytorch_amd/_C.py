@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 4  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 5  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     'lvae_colsum_f32': (C.c_int, [_P, _L, _L, _P, _I, _P]),
     'lvae_normal_stochastic_fwd_f32': (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     'lvae_normal_stochastic_bwd_f32': (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lvae_kl_elementwise_fwd_f32': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    'lvae_kl_elementwise_bwd_f32': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     'lvae_bernoulli_fwd_f32': (C.c_int, [_P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     'lvae_dmol_workspace': (_Z, [_I, _I]),
     'lvae_dmol_ll_fwd_f32': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -244,7 +244,7 @@ static int launch_pw(const PwArgs& a, hipStream_t s) {
   constexpr size_t lds_in = (size_t)(BM * (KT + 4) + (KC ? NT * (KT + 4) : KT * NT)) * sizeof(float);
   constexpr size_t lds_out = (size_t)BM * (NT + 4) * sizeof(float);
   constexpr size_t lds = lds_in > lds_out ? lds_in : lds_out;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {

@@ -161,7 +161,7 @@ int conv1x1_wgrad_try(const lvae_conv_desc* d, const float* dy, float* dw, float
   a.slab_b = db ? a.slab_w + (size_t)nwg * 64 * d->Cout : nullptr;
   const int nb = d->Cout / 32;
   const size_t lds = ((size_t)4 * 2 * nb * 16 * 64 + 4 * nb * 32) * sizeof(float);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)

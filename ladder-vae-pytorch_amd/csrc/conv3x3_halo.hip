@@ -306,7 +306,7 @@ static bool halo_plan(int N, int H, int W, int BM, int cin_t, HaloArgs& a) {
 template <int BM, int CIN_T, bool B_KCONTIG>
 static int launch_halo(HaloArgs a, hipStream_t s) {
   auto kern = conv3x3_halo_kernel<BM, CIN_T, B_KCONTIG>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -368,7 +368,7 @@ int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s) {
   const int BM = halo_select(d, a, ncontig);
   if (BM == 0) return kHaloNotEligible;
   const int cin_t = d->C1 <= 32 ? 32 : 64;
-  static const int dbg = getenv("LVAE_HALO_DEBUG") ? atoi(getenv("LVAE_HALO_DEBUG")) : 0;  // phase-skip switch, profiling only
+  static const int dbg = lvae::debug_phase_switch("LVAE_HALO_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
   a.debug = dbg;
   // n-contiguous weights take precedence when both hold (Cin == 1 cannot reach here)
   const bool kc = !ncontig;

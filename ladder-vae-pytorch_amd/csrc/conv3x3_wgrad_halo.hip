@@ -123,7 +123,7 @@ void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, i
 template <int CIN_T, int NKW>
 static int launch_ws(const WTileArgs& a, hipStream_t s) {
   auto kern = conv_wgrad_ws_kernel<CIN_T, NKW>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -144,7 +144,7 @@ int conv_wgrad_tile_try(const lvae_conv_desc* d, const float* dy, float* dw, flo
   if (!wtile_plan(d, a) || !al16w(dy)) return -1000;
   a.d = *d;
   a.dy = dy;
-  static const int dbg = getenv("LVAE_WG_DEBUG") ? atoi(getenv("LVAE_WG_DEBUG")) : 0;
+  static const int dbg = lvae::debug_phase_switch("LVAE_WG_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
   a.debug = dbg;
   const int ntaps = d->KH * d->KW;
   a.slab_w = static_cast<float*>(workspace);
@@ -172,7 +172,7 @@ void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s);
 template <int CIN_T, int NKW>
 static int launch_ws_grouped(const WTileGroup& g, int n, int max_wgs, size_t lds, hipStream_t s) {
   auto kern = conv_wgrad_ws_grouped_kernel<CIN_T, NKW>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -200,7 +200,7 @@ int conv_wgrad_tile_grouped(const lvae_conv_desc* const* ds, const float* const*
                             void* const* workspace, int n, int kind, hipStream_t s) {
   WTileGroup g;
   ReduceArgs r[kMaxGroup];
-  static const int dbg = getenv("LVAE_WG_DEBUG") ? atoi(getenv("LVAE_WG_DEBUG")) : 0;
+  static const int dbg = lvae::debug_phase_switch("LVAE_WG_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
   int max_wgs = 0;
   size_t lds = 0;
   for (int i = 0; i < n; ++i) {

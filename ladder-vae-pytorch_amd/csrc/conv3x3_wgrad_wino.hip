@@ -209,7 +209,7 @@ static int launch_wg_wino(const WgWinoArgs& a, hipStream_t s) {
   size_t lds = (size_t)2 * (HP * WG_XS + 64 * WG_DS) * sizeof(float);
   const size_t lds_r = (size_t)(4 * 4 * 2 * 16 * 64 + 128) * sizeof(float);
   if (lds < lds_r) lds = lds_r;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -271,7 +271,7 @@ int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const*
   if (lds < lds_r) lds = lds_r;
   const void* kern = W == 8 ? (const void*)conv_wgrad_wino_grouped_kernel<4>
                             : (W == 16 ? (const void*)conv_wgrad_wino_grouped_kernel<8> : (const void*)conv_wgrad_wino_grouped_kernel<16>);
-  static bool attr_set[3] = {false, false, false};
+  static std::atomic<bool> attr_set[3] = {};
   const int slot = W == 8 ? 0 : (W == 16 ? 1 : 2);
   if (!attr_set[slot]) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -426,7 +426,7 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   const size_t lds_r = (size_t)4 * 2 * 32 * WLDO * sizeof(float);
   if (lds < lds_r) lds = lds_r;
   if (lds > 160 * 1024) return -1000;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

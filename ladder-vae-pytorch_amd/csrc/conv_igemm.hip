@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 template <int BM, int BN, bool A_VEC, int B_MODE>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   auto kern = conv_igemm_kernel<BM, BN, A_VEC, B_MODE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

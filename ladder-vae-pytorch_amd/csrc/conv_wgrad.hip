@@ -508,7 +508,7 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
     ta.slab_w = static_cast<float*>(workspace);
     ta.slab_b = db ? ta.slab_w + (size_t)d->N * ta.K * d->Cout : nullptr;
     const size_t lds = ((size_t)(ta.PH * ta.PW * d->C1 + 3) / 4 * 4 + (size_t)d->OH * d->OW * 64) * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_thin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       LVAE_REQUIRE(e == hipSuccess, (int)e, "conv_wgrad_thin: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

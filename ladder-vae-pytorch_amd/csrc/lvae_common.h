@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/lvae_hip.h"
 
@@ -13,6 +16,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 void set_error(const char* fmt, ...);
+
+// Phase-skip switches of the profiling builds (they make a kernel skip stages, i.e. produce wrong results): compiled out of the
+// product library. The remaining LVAE_* environment variables (listed in include/lvae_hip.h) only choose between kernel variants
+// that all pass the parity tests; each is read once, on first use, into a function-local `static const` (thread-safe in C++11).
+inline int debug_phase_switch(const char* name) {
+#ifdef LVAE_PHASE_DEBUG
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+#else
+  (void)name;
+  return 0;
+#endif
+}
 
 #define LVAE_REQUIRE(cond, code, ...)  \
   do {                                 \

@@ -108,11 +108,13 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
 // one 256-thread block per channel: thread k sums chunks k, k+256, ... in double, then a fixed xor-shuffle tree inside each
 // wave and a fixed-order sum of the 4 wave results through LDS
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int chunks, int C, int64_t M,
-                                                          const float* __restrict__ x, const float* gamma, const float* beta,
+                                                          const float* x, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* running_mean, float* running_var,
                                                           float* scale, float* shift, float* mean_out, float* rstd_out) {
   __shared__ double part[4][2];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the pivot row may BE running_mean (ops.ResBlockFn passes it as both): not __restrict__, and read before any store below
+  const float pivot = x[c];
   // per-thread and in-wave sums in fp32 (at most chunks/256 + 6 additions per value, fixed order), doubles from there on
   float af = 0.f, bf = 0.f;
   for (int k = tid; k < chunks; k += 256) {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const double inv_m = 1.0 / (double)M, dm = a * inv_m;  // mean - pivot
   double m2 = b - a * dm;                                 // sum (x - mean)^2
   if (m2 < 0.0) m2 = 0.0;
-  const double mean = (double)x[c] + dm, var = m2 * inv_m;
+  const double mean = (double)pivot + dm, var = m2 * inv_m;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   const float sc = g * rstd;

@@ -151,6 +151,66 @@ __global__ __launch_bounds__(256) void stoch_bwd_kernel(StochBwdArgs a, float* _
   }
 }
 
+
+// Elementwise KL (lib/stochastic.py:88-91 `kl_elementwise`, :209-226 kl_normal_mc): out[n,pix,c] = log q(z) - log p(z) (Monte
+// Carlo) or KL(q || p) (analytical). Not on the training path (TopDownLayer consumes the per-sample sums of stoch_fwd_kernel);
+// kept as its own pass so the training step does not write a tensor nobody reads.
+struct KlElemArgs {
+  const float *p, *q, *z, *g;
+  int p_bcast, q_bcast, HW, Z, analytical;
+  int64_t total;
+};
+
+__global__ __launch_bounds__(256) void kl_elem_fwd_kernel(KlElemArgs a, float* __restrict__ out) {
+  const int Z = a.Z;
+  const int64_t per = (int64_t)a.HW * Z;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / per;
+    const int e = (int)(i - n * per);
+    const int pix = e / Z, c = e - pix * Z;
+    const size_t pb = ((a.p_bcast ? 0 : (size_t)n * a.HW) + pix) * 2 * Z, qb = ((a.q_bcast ? 0 : (size_t)n * a.HW) + pix) * 2 * Z;
+    const float pmu = a.p[pb + c], plv = a.p[pb + Z + c], qmu = a.q[qb + c], qlv = a.q[qb + Z + c];
+    out[i] = a.analytical ? normal_kl(qmu, qlv, pmu, plv) : normal_logprob(a.z[i], qmu, qlv) - normal_logprob(a.z[i], pmu, plv);
+  }
+}
+
+// g = d/d(out); writes dp, dq (full batch shape; the caller reduces a broadcast operand) and dz (Monte Carlo only, else zeros)
+__global__ __launch_bounds__(256) void kl_elem_bwd_kernel(KlElemArgs a, float* __restrict__ dp, float* __restrict__ dq,
+                                                           float* __restrict__ dz) {
+  const int Z = a.Z;
+  const int64_t per = (int64_t)a.HW * Z;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / per;
+    const int e = (int)(i - n * per);
+    const int pix = e / Z, c = e - pix * Z;
+    const size_t pb = ((a.p_bcast ? 0 : (size_t)n * a.HW) + pix) * 2 * Z, qb = ((a.q_bcast ? 0 : (size_t)n * a.HW) + pix) * 2 * Z;
+    const size_t ob = ((size_t)n * a.HW + pix) * 2 * Z;
+    const float pmu = a.p[pb + c], plv = a.p[pb + Z + c], qmu = a.q[qb + c], qlv = a.q[qb + Z + c];
+    const float g = a.g[i];
+    const float ivp = expf(-plv);
+    float dpmu, dplv, dqmu, dqlv, dzz = 0.f;
+    if (a.analytical) {
+      const float dmu = qmu - pmu, vr = expf(qlv - plv);
+      dpmu = -g * dmu * ivp;
+      dplv = g * 0.5f * (1.f - vr - dmu * dmu * ivp);
+      dqmu = g * dmu * ivp;
+      dqlv = g * 0.5f * (vr - 1.f);
+    } else {
+      const float z = a.z[i], ivq = expf(-qlv), dpz = z - pmu, dqz = z - qmu;
+      dpmu = -g * dpz * ivp;
+      dplv = -g * 0.5f * (dpz * dpz * ivp - 1.f);
+      dqmu = g * dqz * ivq;
+      dqlv = g * 0.5f * (dqz * dqz * ivq - 1.f);
+      dzz = g * (dpz * ivp - dqz * ivq);
+    }
+    dp[ob + c] = dpmu;
+    dp[ob + Z + c] = dplv;
+    dq[ob + c] = dqmu;
+    dq[ob + Z + c] = dqlv;
+    if (dz) dz[i] = dzz;
+  }
+}
+
 }  // namespace lvae
 
 using namespace lvae;
@@ -181,5 +241,26 @@ extern "C" int lvae_normal_stochastic_bwd_f32(const float* p, int32_t p_bcast, c
   const int64_t total = (int64_t)N * HW * Z;
   hipLaunchKernelGGL(stoch_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, dp, dq);
   LVAE_LAUNCH_CHECK("normal_stochastic_bwd");
+  return 0;
+}
+
+extern "C" int lvae_kl_elementwise_fwd_f32(const float* p, int32_t p_bcast, const float* q, int32_t q_bcast, const float* z,
+                                           int32_t N, int32_t HW, int32_t Z, int32_t analytical_kl, float* out, void* stream) {
+  LVAE_REQUIRE(p && q && out && N > 0 && HW > 0 && Z > 0, LVAE_EINVAL, "lvae_kl_elementwise_fwd_f32: bad args");
+  LVAE_REQUIRE(analytical_kl || z, LVAE_EINVAL, "lvae_kl_elementwise_fwd_f32: z missing");
+  KlElemArgs a{p, q, z, nullptr, p_bcast, q_bcast, HW, Z, analytical_kl, (int64_t)N * HW * Z};
+  hipLaunchKernelGGL(kl_elem_fwd_kernel, dim3(grid_for(a.total, 256)), dim3(256), 0, (hipStream_t)stream, a, out);
+  LVAE_LAUNCH_CHECK("kl_elementwise_fwd");
+  return 0;
+}
+
+extern "C" int lvae_kl_elementwise_bwd_f32(const float* p, int32_t p_bcast, const float* q, int32_t q_bcast, const float* z,
+                                           const float* g, int32_t N, int32_t HW, int32_t Z, int32_t analytical_kl, float* dp,
+                                           float* dq, float* dz, void* stream) {
+  LVAE_REQUIRE(p && q && g && dp && dq && N > 0 && HW > 0 && Z > 0, LVAE_EINVAL, "lvae_kl_elementwise_bwd_f32: bad args");
+  LVAE_REQUIRE(analytical_kl || z, LVAE_EINVAL, "lvae_kl_elementwise_bwd_f32: z missing");
+  KlElemArgs a{p, q, z, g, p_bcast, q_bcast, HW, Z, analytical_kl, (int64_t)N * HW * Z};
+  hipLaunchKernelGGL(kl_elem_bwd_kernel, dim3(grid_for(a.total, 256)), dim3(256), 0, (hipStream_t)stream, a, dp, dq, dz);
+  LVAE_LAUNCH_CHECK("kl_elementwise_bwd");
   return 0;
 }

@@ -5,6 +5,7 @@ happens in Python or in torch ops here: every function launches hand-written HIP
 stream. Buffers (outputs, workspaces) come from torch's caching allocator, which is graph-capture safe.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -92,11 +93,30 @@ class _PreparedWeights:
     def stamp(self, weight):
         return (weight._version, self.epoch)
 
+    @staticmethod
+    def _alive(ent):
+        """The entry's weight tensor still exists and still lives where the entry's raw pointers say (a model that was dropped, or
+        re-packed by .to(), leaves entries behind that must neither pin its arena nor be transformed again)."""
+        w = ent['weight']()
+        return w is not None and w.data_ptr() == ent['base']
+
+    def evict_dead(self):
+        dead = [k for k, e in self.entries.items() if not self._alive(e)]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.table = None
+        return len(dead)
+
     def attach(self, d, weight, device, need):
         key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, device.index)
         ent = self.entries.get(key)
+        if ent is not None and not self._alive(ent):   # the address was recycled for another tensor
+            del self.entries[key]
+            self.table = None
+            ent = None
         if ent is None:
-            ent = {'weight': weight, 'U': torch.empty(int(need), dtype=torch.uint8, device=device), 'stamp': None, 'entry': None}
+            ent = {'weight': weakref.ref(weight), 'base': weight.data_ptr(), 'U': torch.empty(int(need), dtype=torch.uint8, device=device), 'stamp': None, 'entry': None}
             d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
             raw = (C.c_char * _C.load().lvae_conv2d_prepare_entry_bytes())()
             call('lvae_conv2d_prepare_entry', C.byref(d), C.cast(raw, C.c_void_p))
@@ -105,10 +125,12 @@ class _PreparedWeights:
             self.entries[key] = ent
             self.table = None
         d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
-        d.workspace_ready = 1 if (self.enabled and ent['stamp'] == self.stamp(ent['weight'])) else 0
+        d.workspace_ready = 1 if (self.enabled and ent['stamp'] == self.stamp(weight)) else 0
 
     def prepare_all(self):
         """One launch that (re)writes every registered buffer from the current weights. Returns the number of entries."""
+        if not torch.cuda.is_current_stream_capturing():
+            self.evict_dead()   # (a captured step keeps its table: the replayed launch reads the pointers it was captured with)
         if not self.entries or not self.enabled:
             return 0
         by_dev = {}
@@ -127,7 +149,8 @@ class _PreparedWeights:
             with torch.cuda.device(dev):
                 call('lvae_conv2d_prepare_weights', t.data_ptr(), n, max_cout, stream_ptr())
             for e in ents:
-                e['stamp'] = self.stamp(e['weight'])
+                w = e['weight']()
+                e['stamp'] = self.stamp(w) if w is not None else None
         return len(self.entries)
 
     def weights_written(self):
@@ -460,6 +483,25 @@ def normal_stochastic_bwd(p, q, eps, z, dz, g_lp, g_lq, g_kl, g_ks, mode, analyt
     call('lvae_normal_stochastic_bwd_f32', ptr(p), p_bcast, ptr(q), ptr(eps), ptr(z), ptr(dz), ptr(g_lp), ptr(g_lq),
          ptr(g_kl), ptr(g_ks), N, H * W, Z, mode, int(bool(analytical_kl)), ptr(dp), ptr(dq), stream_ptr())
     return dp, dq
+
+
+def kl_elementwise_fwd(p, q, z, analytical_kl):
+    """p, q (N|1,H,W,2Z), z (N,H,W,Z) -> (N,H,W,Z): log q(z) - log p(z), or KL(q||p) when analytical_kl."""
+    N, H, W, Z = z.shape
+    out = torch.empty_like(z)
+    call('lvae_kl_elementwise_fwd_f32', ptr(p), int(p.shape[0] == 1 and N > 1), ptr(q), int(q.shape[0] == 1 and N > 1), ptr(z),
+         N, H * W, Z, int(bool(analytical_kl)), ptr(out), stream_ptr())
+    return out
+
+
+def kl_elementwise_bwd(p, q, z, g, analytical_kl, need_dz=True):
+    N, H, W, Z = z.shape
+    dp = torch.empty((N, H, W, 2 * Z), dtype=torch.float32, device=z.device)
+    dq = torch.empty_like(dp)
+    dz = torch.empty_like(z) if need_dz else None
+    call('lvae_kl_elementwise_bwd_f32', ptr(p), int(p.shape[0] == 1 and N > 1), ptr(q), int(q.shape[0] == 1 and N > 1), ptr(z),
+         ptr(g), N, H * W, Z, int(bool(analytical_kl)), ptr(dp), ptr(dq), ptr(dz), stream_ptr())
+    return dp, dq, dz
 
 
 # ----------------------------------------------------------------------------------------------------------------

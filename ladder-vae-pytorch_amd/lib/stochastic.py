@@ -25,7 +25,9 @@ class NormalStochasticBlock2d(nn.Module):
         self.conv_out = Conv2dParams(c_vars, c_out, kernel, padding=pad)
 
     def forward(self, p_params, q_params=None, forced_latent=None, use_mode=False, force_constant_output=False,
-                analytical_kl=False, noise=None, n_img=None):
+                analytical_kl=False, noise=None, n_img=None, need_kl_elementwise=True):
+        """need_kl_elementwise=False (engine-only keyword, used by TopDownLayer which drops that key, models/lvae_layers.py:163-170):
+        skip the pass that materialises `kl_elementwise` (lib/stochastic.py:88-91); the per-sample and per-pixel sums do not need it."""
         assert (forced_latent is None) or (not use_mode)
         if self.transform_p_params:
             p_params = self.conv_in_p(p_params)
@@ -56,13 +58,12 @@ class NormalStochasticBlock2d(nn.Module):
                 'kl_elementwise': None, 'kl_samplewise': None, 'kl_spatial': None}
         if q_params is not None:
             data['logprob_q'], data['kl_samplewise'], data['kl_spatial'] = outs[2], outs[3], outs[4]
+            if need_kl_elementwise:
+                data['kl_elementwise'] = ops.KlElementwiseFn.apply(z, p_params, q_params, bool(analytical_kl))
         return out, data
 
 
 def kl_normal_mc(z, p_mulv, q_mulv):
-    """lib/stochastic.py:209-226 on the HIP kernel: elementwise log q(z) - log p(z). NHWC tensors, mu|logvar on C."""
-    N, H, W, Z = z.shape
-    # forced-latent mode returns z unchanged and the MC KL summed per sample; elementwise values are not part of the
-    # training path, so expose the per-sample sum (what every call site consumes)
-    outs = K.normal_stochastic_fwd(p_mulv.contiguous(), q_mulv.contiguous(), z.contiguous(), 2, False, Z, N)
-    return outs[3]
+    """lib/stochastic.py:209-226 on the HIP kernel: elementwise log q(z) - log p(z). NHWC tensors (mu | logvar on the channel
+    axis); p_mulv / q_mulv may have batch size 1 (broadcast over the batch of z), as the reference's broadcasting allows."""
+    return ops.KlElementwiseFn.apply(z.contiguous(), p_mulv.contiguous(), q_mulv.contiguous(), False)

@@ -210,7 +210,9 @@ class LadderVAE(nn.Module):
         """models/lvae.py:216-227. x: padded image (N,C,Hp,Wp); returns the list of per-level NCHW feature maps."""
         self._begin(x)
         x_pad = K.pad_crop(x.contiguous().float(), True, x.shape[2:], False)
-        return [_nchw(b) for b in self._bottomup(x_pad)]
+        out = [_nchw(b) for b in self._bottomup(x_pad)]
+        self.noise.end()  # the next call draws fresh dropout masks
+        return out
 
     def _topdown(self, bu_values=None, n_img_prior=None, mode_layers=None, constant_layers=None, forced_latent=None):
         if mode_layers is None:
@@ -261,6 +263,7 @@ class LadderVAE(nn.Module):
         if bu_values is not None:
             bu_values = [b.permute(0, 2, 3, 1).contiguous() for b in bu_values]
         out, data = self._topdown(bu_values, n_img_prior, mode_layers, constant_layers, forced_latent)
+        self.noise.end()  # every call returns a fresh sample, as the reference's rsample() does
         data = dict(data)
         data['z'] = [_nchw(t) for t in data['z']]
         return _nchw(out), data

@@ -169,7 +169,8 @@ class TopDownLayer(nn.Module):
             q_params = None
         x, data_stoch = self.stochastic(p_params=p_params, q_params=q_params, forced_latent=forced_latent,
                                         use_mode=use_mode, force_constant_output=force_constant_output,
-                                        analytical_kl=self.analytical_kl, noise=noise, n_img=n_img)
+                                        analytical_kl=self.analytical_kl, noise=noise, n_img=n_img,
+                                        need_kl_elementwise=False)
         if self.stochastic_skip and not self.is_top_layer:
             x = self.skip_connection_merger(x, skip_connection_input, noise)
         x_pre_residual = x

@@ -353,6 +353,29 @@ class NormalStochFn(Function):
         return dp, dq, None, None, None, None, None
 
 
+class KlElementwiseFn(Function):
+    """`kl_elementwise` of lib/stochastic.py:88-91 / kl_normal_mc :209-226 as a differentiable node (off the training path)."""
+
+    @staticmethod
+    def forward(ctx, z, p, q, analytical):
+        ctx.analytical = analytical
+        ctx.save_for_backward(z, p, q)
+        return K.kl_elementwise_fwd(p, q, z, analytical)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, p, q = ctx.saved_tensors
+        dp, dq, dz = K.kl_elementwise_bwd(p, q, z, _c(g), ctx.analytical, need_dz=ctx.needs_input_grad[0])
+        out = []
+        for t, d in ((p, dp), (q, dq)):
+            if t.shape[0] == 1 and d.shape[0] > 1:
+                red = torch.empty_like(t)
+                K.colsum(d.view(d.shape[0], -1), red.view(-1), False)
+                d = red
+            out.append(d)
+        return dz, out[0], out[1], None
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class BernoulliFn(Function):
     """lib/likelihoods.py:60-78: returns ll (N,) [differentiable], mean, mode, sample (NHWC, no grad)."""

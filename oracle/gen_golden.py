@@ -235,8 +235,104 @@ def run_ops():
     print('ops              %7.1f KB' % (os.path.getsize(path) / 1024))
 
 
+def run_forced():
+    """topdown_pass(bu_values, forced_latent=[...]) of the reference (models/lvae.py:229-315, lib/stochastic.py:66-67): layers 0 and 2
+    forced, layer 1 sampled; eval mode, so the tape holds the one normal draw and the likelihood draws are not involved."""
+    cfg, batch, seed, _ = CASES['tiny_cifar']
+    torch.manual_seed(seed)
+    model = LadderVAE(**cfg)
+    g = torch.Generator().manual_seed(seed + 2000)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith('running_mean'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif k.endswith('running_var'):
+                v.copy_(1.0 + 0.2 * torch.rand(v.shape, generator=g))
+            elif k.endswith('top_prior_params'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    store = {}
+    flat('sd', {k: v.clone() for k, v in model.state_dict().items()}, store)
+    x = synth_x(cfg, batch, seed)
+    store['x'] = x.numpy()
+    model.eval()
+    with torch.no_grad():
+        z_shapes = [tuple(z.shape) for z in model(x)['z']]
+        forced = [0.7 * torch.randn(z_shapes[0], generator=g), None, 0.7 * torch.randn(z_shapes[2], generator=g)]
+        bu = model.bottomup_pass(model.pad_input(x))
+        torch.manual_seed(seed + 3)
+        rec = RecordRNG()
+        with rec:
+            out, data = model.topdown_pass(bu, forced_latent=forced)
+    flat('bu', bu, store)
+    flat('forced', {str(i): f for i, f in enumerate(forced) if f is not None}, store)
+    flat('tape', rec.tape, store)
+    store['out'] = out.numpy()
+    flat('data', {'z': data['z'], 'kl': data['kl'], 'kl_spatial': data['kl_spatial'], 'logprob_p': data['logprob_p']}, store)
+    store['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, 'tiny_forced.npz')
+    np.savez_compressed(path, **store)
+    print('tiny_forced      %7.1f KB  tape=%d' % (os.path.getsize(path) / 1024, len(rec.tape)))
+
+
+def run_stoch():
+    """NormalStochasticBlock2d (lib/stochastic.py:7-112) called directly — every key of its data dict incl. `kl_elementwise`, Monte-Carlo
+    and analytical, sampled / forced / mode, with input gradients through kl_elementwise — and kl_normal_mc (:209-226) with a
+    batch-broadcast prior."""
+    store = {}
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(22)
+    blk = ref_stoch.NormalStochasticBlock2d(c_in=8, c_vars=4, c_out=8)
+    flat('sd', {k: v.clone() for k, v in blk.state_dict().items()}, store)
+    p_in = torch.randn(3, 8, 4, 4, generator=g)
+    q_in = torch.randn(3, 8, 4, 4, generator=g)
+    forced = 0.5 * torch.randn(3, 4, 4, 4, generator=g)
+    w_el = torch.randn(3, 4, 4, 4, generator=g)
+    store['p_in'], store['q_in'], store['forced'], store['w_el'] = p_in.numpy(), q_in.numpy(), forced.numpy(), w_el.numpy()
+    for tag, kw in (('mc', {}), ('an', {'analytical_kl': True}), ('forced', {'forced_latent': forced}), ('mode', {'use_mode': True})):
+        pi, qi = p_in.clone().requires_grad_(True), q_in.clone().requires_grad_(True)
+        torch.manual_seed(23)
+        rec = RecordRNG()
+        with rec:
+            out, data = blk(pi, qi, **kw)
+        blk.zero_grad()
+        ((data['kl_elementwise'] * w_el).sum() + 0.1 * out.sum()).backward()
+        flat(tag + '.tape', rec.tape, store)
+        store[tag + '.out'] = out.detach().numpy()
+        flat(tag + '.data', data, store)
+        store[tag + '.dp_in'], store[tag + '.dq_in'] = pi.grad.numpy(), qi.grad.numpy()
+        flat(tag + '.grad', {k: v.grad.clone() for k, v in blk.named_parameters()}, store)
+    z = torch.randn(3, 4, 4, 4, generator=g)
+    p1 = torch.randn(1, 8, 4, 4, generator=g)
+    q3 = torch.randn(3, 8, 4, 4, generator=g)
+    store['klmc.z'], store['klmc.p'], store['klmc.q'] = z.numpy(), p1.numpy(), q3.numpy()
+    store['klmc.out'] = ref_stoch.kl_normal_mc(z, p1, q3).numpy()
+    path = os.path.join(OUT, 'stoch.npz')
+    np.savez_compressed(path, **store)
+    print('stoch            %7.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def run_celeba():
+    """CelebA input transform of experiment/data.py:76-80 — transforms.CenterCrop(148), transforms.Resize((64, 64)), ToTensor. torchvision
+    is absent here; both transforms delegate to Pillow (`Image.crop` with torchvision's rounded offsets, `Image.resize(..., BILINEAR)`),
+    which IS installed, so the expected outputs below come from Pillow itself on random and smooth 218x178 images."""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (4, 218, 178, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:218, 0:178]
+    imgs[3] = np.stack([yy * 255 / 217, xx * 255 / 177, (yy + xx) * 255 / 394], -1).astype(np.uint8)
+    out = []
+    for im in imgs:
+        top, left = int(round((218 - 148) / 2.0)), int(round((178 - 148) / 2.0))   # torchvision.transforms.functional.center_crop
+        pil = Image.fromarray(im).crop((left, top, left + 148, top + 148)).resize((64, 64), Image.BILINEAR)
+        out.append(np.asarray(pil, dtype=np.uint8))
+    path = os.path.join(OUT, 'celeba_resize.npz')
+    np.savez_compressed(path, imgs=imgs, out=np.stack(out))
+    print('celeba_resize    %7.1f KB' % (os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)  # one thread: the reference output is then bit-reproducible (SURVEY.md §8c)
-    names = sys.argv[1:] or (list(CASES) + ['ops'])
+    names = sys.argv[1:] or (list(CASES) + ['ops', 'tiny_forced', 'stoch', 'celeba_resize'])
+    special = {'ops': run_ops, 'tiny_forced': run_forced, 'stoch': run_stoch, 'celeba_resize': run_celeba}
     for n in names:
-        run_ops() if n == 'ops' else run_case(n)
+        special[n]() if n in special else run_case(n)

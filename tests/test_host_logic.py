@@ -1,4 +1,6 @@
 """Host-side logic of the engine that needs no GPU: module tree / state_dict scheme, seeded init, argument checks."""
+import os
+
 import pytest
 import torch
 
@@ -119,3 +121,32 @@ def test_data_pipeline_formats(tmp_path):
     assert tuple(x.shape) == (4, 3, 32, 32) and float(x.max()) <= 1.0
     np.testing.assert_allclose(x.numpy().reshape(4, 3072), imgs['test_batch'].astype(np.float32) / 255.0)
     assert len(dl.train.dataset) == 20 and dl.color_ch == 3
+
+
+def test_celeba_transform_matches_pillow_fixture_and_loader(tmp_path):
+    """experiment/data.py:76-89: CenterCrop(148) + Resize((64,64)) + ToTensor from pre-decoded arrays; the expected pixels were
+    produced by Pillow (what torchvision delegates to) in oracle/gen_golden.py."""
+    import types
+    import numpy as np
+    import lvae_amd  # noqa: F401
+    from lvae_amd import data as D
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'celeba_resize.npz'))
+    got = D.celeba_transform_uint8(z['imgs'])
+    assert got.dtype == np.uint8 and np.array_equal(got, z['out'])          # bit exact
+    folder = tmp_path / 'celeba'
+    folder.mkdir()
+    imgs = np.concatenate([z['imgs']] * 3)                                   # 12 images: 6 train, 3 valid, 3 test
+    np.save(folder / 'celeba_aligned_uint8.npy', imgs)
+    split = [0, 0, 1, 2] * 3
+    with open(folder / 'list_eval_partition.txt', 'w') as f:
+        for i, s in enumerate(split):
+            f.write('%06d.jpg %d\n' % (i + 1, s))
+    args = types.SimpleNamespace(dataset_name='celeba', batch_size=4, test_batch_size=2)
+    dl = D.DatasetLoader(args, folder=str(folder))
+    assert tuple(dl.data_shape) == (3, 64, 64) and dl.color_ch == 3 and tuple(dl.img_size) == (64, 64)
+    assert len(dl.train.dataset) == 6 and len(dl.test.dataset) == 3
+    xb, _ = next(iter(dl.test))
+    assert xb.dtype == torch.float32 and tuple(xb.shape) == (2, 3, 64, 64)
+    want = torch.from_numpy(z['out'][2]).permute(2, 0, 1).float() / 255    # first 'valid' image is imgs[2]
+    assert torch.equal(xb[0], want)
+    assert len(list(dl.train)) == 1                                          # drop_last: 6 // 4

@@ -115,3 +115,45 @@ def test_padded_size_and_prior_shape_tables():
         assert R.get_top_prior_param_shape(cfg) == want_prior
     with pytest.raises(RuntimeError):
         R.get_padded_size(cfg, (1, 2, 3))
+
+
+def test_oracle_forced_latent_topdown_matches_reference():
+    """topdown_pass(bu_values, forced_latent=[z0, None, z2]) — models/lvae.py:229-315, lib/stochastic.py:66-67."""
+    g = load_golden('tiny_forced')
+    sd = g.state_dict()
+    forced = [g.raw.get('forced.%d' % i) for i in range(3)]
+    forced = [None if f is None else torch.from_numpy(f) for f in forced]
+    tape = R.Tape(g.seq('tape'))
+    with torch.no_grad():
+        out, data = R.topdown_pass(sd, g.cfg, tape, False, bu_values=g.seq('bu'), forced_latent=forced)
+    assert tape.exhausted()
+    close(out, g.t('out'), atol=1e-4)
+    close(data['logprob_p'], g.t('data.logprob_p'), atol=1e-3)
+    for i in range(3):
+        close(data['z'][i], g.t('data.z.%d' % i))
+        close(data['kl'][i], g.t('data.kl.%d' % i), atol=1e-3)
+        close(data['kl_spatial'][i], g.t('data.kl_spatial.%d' % i), atol=1e-4)
+    assert torch.equal(data['z'][0], forced[0]) and torch.equal(data['z'][2], forced[2])
+
+
+@pytest.mark.parametrize('tag', ['mc', 'an', 'forced', 'mode'])
+def test_oracle_stochastic_block_matches_reference(tag):
+    """Every key of NormalStochasticBlock2d's data dict (lib/stochastic.py:102-112) incl. kl_elementwise."""
+    g = load_golden('stoch')
+    sd = {'s.' + k: v for k, v in g.state_dict().items()}
+    cfg = {'analytical_kl': tag == 'an'}
+    tape = R.Tape(g.seq(tag + '.tape'))
+    out, data = R.stochastic_block(sd, 's', g.t('p_in'), g.t('q_in'), cfg, True, tape,
+                                   forced_latent=g.t('forced') if tag == 'forced' else None, use_mode=tag == 'mode')
+    assert tape.exhausted()
+    close(out, g.t(tag + '.out'))
+    for k in ('z', 'p_params', 'q_params', 'logprob_p', 'logprob_q', 'kl_elementwise', 'kl_samplewise', 'kl_spatial'):
+        close(data[k], g.t('%s.data.%s' % (tag, k)), atol=1e-4)
+
+
+def test_oracle_kl_normal_mc_broadcast():
+    g = load_golden('stoch')
+    z, p, q = g.t('klmc.z'), g.t('klmc.p'), g.t('klmc.q')
+    p_mu, p_lv = p.chunk(2, 1)
+    q_mu, q_lv = q.chunk(2, 1)
+    close(R.normal_log_prob(z, q_mu, q_lv) - R.normal_log_prob(z, p_mu, p_lv), g.t('klmc.out'))
