@@ -25,10 +25,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-CIFAR15 = dict(color_ch=3, z_dims=[32] * 15, blocks_per_layer=4, downsample=[0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0],
-               nonlin='elu', merge_type='residual', batchnorm=True, stochastic_skip=True, n_filters=64, dropout=0.2,
-               free_bits=1.0, learn_top_prior=True, img_shape=(32, 32), likelihood_form='discr_log_mix',
-               res_block_type='bacdbacd', gated=True, no_initial_downscaling=False, analytical_kl=False)
+import lvae_amd  # noqa: E402,F401
+from lvae_amd.configs import CIFAR15, MNIST3  # noqa: E402  (the same dicts the full-size parity tests build their models from)
+
 PEAK_MFMA_F32 = 157.3  # TFLOP/s, MI355X_MICROARCH.md
 
 
@@ -180,7 +179,13 @@ def main():
     arena = model.pack()
     ldist.broadcast_flat(arena.params)
     opt = Adamax(model, lr=3e-4)
-    allreduce = ldist.GradAllReduce(arena.grads) if (world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1') else None
+    allreduce = (ldist.GradAllReduce(arena.grads, segments=arena.segments)
+                 if (world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1') else None)
+    if world > max(1, torch.cuda.device_count()) and not args.no_graph:
+        # rehearsal with several ranks on ONE device: two processes replaying multi-thousand-node graphs on one GPU time-slice
+        # through compute-wave save/restore (seconds per step, gpurun_out/ddp2g.log of round 1); launch eagerly instead
+        log('ranks share a device: hipGraph replay disabled')
+        args.no_graph = True
     step = TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce, async_wgrad=args.async_wgrad,
                      wgrad_streams=args.wgrad_streams, wgrad_group_rows=args.wgrad_group_rows or None)
 

@@ -9,6 +9,13 @@ loads in forward (Cout contiguous) and dgrad (same memory, k = Cout contiguous).
 
 Trainable parameters come first ([0, n_train)), frozen ones (e.g. a non-learned top prior) after, so Adamax and the
 all-reduce work on the prefix and the L2 norm on everything.
+
+Within the trainable prefix the parameters are laid out by GRADIENT-COMPLETION ORDER (`segment_of`: the model's
+`grad_segments()`, i.e. reverse execution order: likelihood head, final top-down blocks, top-down layers 0..L-1, bottom-up
+layers L-1..0, stem) — not by registration order (models/lvae.py:74,87-88,156,159-167 of the reference registers bottom-up and
+top-down layers interleaved). A data-parallel bucket is then a contiguous slice of the gradient arena that is complete as soon
+as backward has left its last segment (`segments` = [(lo, hi)] in that order), so its all-reduce can start while backward
+continues (dist.GradAllReduce). The state_dict order is untouched (it follows module registration).
 """
 import torch
 
@@ -22,7 +29,7 @@ def _round(n):
 
 
 class ParamArena:
-    def __init__(self, model, device):
+    def __init__(self, model, device, segment_of=None):
         conv_w = {}
         for mod in model.modules():
             if isinstance(mod, Conv2dParams):
@@ -30,6 +37,11 @@ class ParamArena:
         named = [(k, p) for k, p in model.named_parameters()]
         train = [(k, p) for k, p in named if p.requires_grad]
         frozen = [(k, p) for k, p in named if not p.requires_grad]
+        seg_ids = [0] * len(train)
+        if segment_of is not None:
+            order = sorted(range(len(train)), key=lambda i: segment_of(train[i][0]))   # stable: registration order inside a segment
+            train = [train[i] for i in order]
+            seg_ids = [segment_of(k) for k, _ in train]
         self.names = [k for k, _ in train + frozen]
         sizes = [_round(p.numel()) for _, p in train + frozen]
         self.n_train = sum(_round(p.numel()) for _, p in train)
@@ -37,6 +49,13 @@ class ParamArena:
         self.params = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=device)
         self.slots = {}
+        self.segments = []          # [(lo, hi)] element ranges of the gradient arena, one per segment, in completion order
+        lo = 0
+        for i, sz in enumerate(sizes[:len(train)]):
+            if i + 1 == len(train) or seg_ids[i + 1] != seg_ids[i]:
+                hi = sum(sizes[:i + 1])
+                self.segments.append((lo, hi))
+                lo = hi
         off = 0
         for (k, p), sz in zip(train + frozen, sizes):
             n = p.numel()

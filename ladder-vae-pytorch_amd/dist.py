@@ -47,33 +47,101 @@ def bucket_slices(n, bucket_elems):
     return out
 
 
-class GradAllReduce:
-    """SUM all-reduce of a flat gradient buffer in buckets on a side stream; `scale` = 1/world for the optimiser."""
+def make_buckets(segments, bucket_elems):
+    """Merge consecutive gradient segments (arena.segments, in completion order) into buckets of at least `bucket_elems` elements.
+    Returns [(lo, hi, last_segment_index)]: bucket k is complete when backward has left segment `last_segment_index`."""
+    out, lo = [], None
+    for i, (a, b) in enumerate(segments):
+        if lo is None:
+            lo = a
+        if b - lo >= bucket_elems or i + 1 == len(segments):
+            out.append((lo, b, i))
+            lo = None
+    return out
 
-    def __init__(self, flat_grads, group=None, bucket_mb=16.0):
+
+class GradAllReduce:
+    """SUM all-reduce of the flat gradient arena, `scale` = 1/world for the optimiser.
+
+    The arena is laid out in gradient-completion order (arena.py), so a bucket is a contiguous slice that is final as soon as
+    backward has left its last segment. `segment_done(i)` — called from the backward of the model's segment markers
+    (ops.SegmentMarkFn) — forks the side stream off the launch stream at that point and enqueues the bucket's all-reduce
+    there, while backward keeps issuing kernels on the launch stream; `finish()` enqueues what is left (the last bucket: stem)
+    and joins the side stream back, after which the optimiser may run. Inside a hipGraph capture the fork/join become graph
+    edges and the RCCL kernels graph nodes, so the whole step (backward, exchange, Adamax) replays as one graph.
+
+    `run()` is the non-overlapped form (everything after backward), kept for LVAE_DDP_MODE=split and for CPU/gloo tensors.
+    """
+
+    def __init__(self, flat_grads, group=None, bucket_mb=8.0, segments=None):
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = os.environ.get('LVAE_FORCE_DIST') == '1' and dist.is_initialized()
-        self.buckets = bucket_slices(flat_grads.numel(), max(1, int(bucket_mb * (1 << 20) / 4)))
+        elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        n = flat_grads.numel()
+        if segments:
+            assert segments[0][0] == 0 and segments[-1][1] == n and all(a[1] == b[0] for a, b in zip(segments, segments[1:]))
+            self.buckets = make_buckets(segments, elems)
+        else:
+            self.buckets = [(lo, hi, None) for lo, hi in bucket_slices(n, elems)]
+        self.by_segment = {last: k for k, (_, _, last) in enumerate(self.buckets) if last is not None}
         self.on_gpu = flat_grads.is_cuda
+        # RCCL collectives are plain kernel launches on the stream and can be captured into a hipGraph; gloo cannot
+        self.capturable = dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.stream = torch.cuda.Stream(device=flat_grads.device) if self.on_gpu else None
         self.scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat_grads.device)
+        self.overlap = segments is not None and os.environ.get('LVAE_DDP_MODE', 'overlap') != 'split'
+        self.next_bucket = 0
+        self.launched = []          # bucket indices in launch order of the current step (tests look at it)
 
-    def run(self):
-        """Reduce all buckets; the caller's current stream waits for completion (no host sync)."""
-        if (self.world == 1 and not self.force) or os.environ.get('LVAE_SKIP_ALLREDUCE') == '1':  # second: profiling only
+    @property
+    def active(self):
+        return (self.world > 1 or self.force) and os.environ.get('LVAE_SKIP_ALLREDUCE') != '1'   # second: profiling only
+
+    def begin_step(self):
+        self.next_bucket = 0
+        self.launched = []
+
+    def _reduce(self, k):
+        lo, hi, _ = self.buckets[k]
+        dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self.launched.append(k)
+
+    def _launch_through(self, k):
+        """Enqueue buckets next_bucket..k (in order: every rank issues the same sequence of collectives)."""
+        if k < self.next_bucket:
             return
         if not self.on_gpu:
-            for lo, hi in self.buckets:
-                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            for b in range(self.next_bucket, k + 1):
+                self._reduce(b)
+        else:
+            cur = torch.cuda.current_stream(self.flat.device)
+            self.stream.wait_stream(cur)           # fork: everything issued so far (this bucket's last gradient kernel included)
+            with torch.cuda.stream(self.stream):
+                for b in range(self.next_bucket, k + 1):
+                    self._reduce(b)
+        self.next_bucket = k + 1
+
+    def segment_done(self, seg):
+        if not (self.active and self.overlap):
             return
-        cur = torch.cuda.current_stream(self.flat.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            for lo, hi in self.buckets:
-                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-        cur.wait_stream(self.stream)
+        k = self.by_segment.get(seg)
+        if k is not None:
+            self._launch_through(k)
+
+    def finish(self):
+        """After backward: exchange whatever has not been enqueued yet and make the launch stream wait for all of it."""
+        if not self.active:
+            return
+        self._launch_through(len(self.buckets) - 1)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+
+    def run(self):
+        """Reduce all buckets after backward; the caller's current stream waits for completion (no host sync)."""
+        self.begin_step()
+        self.finish()
 
 
 def broadcast_flat(flat, src=0, group=None):

@@ -3,7 +3,9 @@
 The eager schedule of one CIFAR-15 step is several thousand dependent launches; replaying a
 captured graph removes the Python / launch overhead without a tracing compiler. RNG state lives in device memory
 and is advanced by a kernel inside the graph, so every replay draws fresh noise. With world_size > 1 the gradient
-all-reduce sits between two graphs (fwd+bwd | all-reduce on a side stream | Adamax).
+all-reduce is part of the same graph: each bucket of the (completion-ordered) gradient arena is exchanged on a side stream as
+soon as backward has left it (dist.GradAllReduce), and Adamax waits for the last one. LVAE_DDP_MODE=split keeps the exchange
+outside the graphs instead (fwd+bwd graph | eager all-reduce | Adamax graph): collectives that are not captured.
 """
 import torch
 
@@ -50,11 +52,18 @@ class TrainStep:
         if allreduce is not None and allreduce.world > 1:
             optimizer._state()
             optimizer.gscale = allreduce.scale
+        if allreduce is not None and allreduce.active and allreduce.on_gpu and not allreduce.capturable:
+            self.use_graph, self.eager_left = False, -1   # gloo stages device buffers through the host: cannot be part of a graph
+        self.overlap = allreduce is not None and allreduce.active and allreduce.overlap
+        if self.overlap:
+            model.grad_tracker = allreduce   # the model's segment markers report to it during backward
 
     def _fwd_bwd(self, x):
         self.opt.zero_grad()
         K.prepared.prepare_all()  # one launch: transformed weights of every Winograd convolution seen so far
         out = forward_pass(self.model, x, self.beta)
+        if self.allreduce is not None:
+            self.allreduce.begin_step()
         ops.set_wgrad_stream(self.side)
         ops.set_wgrad_grouping(self.wgrad_group_rows)
         try:
@@ -64,6 +73,8 @@ class TrainStep:
             out['loss'].backward()
             ops.flush_wgrad_group()
             ops.join_wgrad_stream()
+            if self.overlap:
+                self.allreduce.finish()  # last bucket + join: the gradients are summed over ranks from here on
         finally:
             ops.set_wgrad_grouping(None)
             ops.set_wgrad_stream(None)
@@ -71,7 +82,7 @@ class TrainStep:
 
     def _eager(self, x):
         out = self._fwd_bwd(x)
-        if self.allreduce is not None:
+        if self.allreduce is not None and not self.overlap:
             self.allreduce.run()
         self.opt.step()
         return out
@@ -79,7 +90,7 @@ class TrainStep:
     def _capture(self, x):
         self.static_x = torch.empty_like(x)
         self.static_x.copy_(x)
-        fused = self.allreduce is None or (self.allreduce.world == 1 and not getattr(self.allreduce, 'force', False))
+        fused = self.allreduce is None or not self.allreduce.active or self.overlap
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures

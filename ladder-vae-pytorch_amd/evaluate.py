@@ -50,6 +50,13 @@ def iw_log_likelihood(model, x, n_samples):
         model.train(was_training)
 
 
+def reduce_eval_sums(tot, process_group=None):
+    """[sum of IW bounds, sum of ELBOs, image count] of this rank's shard -> totals over all ranks (one all-reduce)."""
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
+        torch.distributed.all_reduce(tot, group=process_group)
+    return tot
+
+
 @torch.no_grad()
 def evaluate(model, batches, n_samples, process_group=None):
     """Mean ELBO and IW bound over an iterable of image batches (each rank passes ITS shard of the test set)."""
@@ -59,8 +66,7 @@ def evaluate(model, batches, n_samples, process_group=None):
         tot[0] += iw.double().sum()
         tot[1] += elbo.double().sum()
         tot[2] += x.shape[0]
-    if torch.distributed.is_initialized() and torch.distributed.get_world_size(process_group) > 1:
-        torch.distributed.all_reduce(tot, group=process_group)
+    tot = reduce_eval_sums(tot, process_group)
     n = float(tot[2])
     return {'elbo/elbo': float(tot[1]) / n, 'elbo/elbo_IW_%d' % n_samples: float(tot[0]) / n, 'n_images': int(n)}
 

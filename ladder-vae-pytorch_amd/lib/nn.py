@@ -6,8 +6,6 @@ Modules take and return NHWC tensors (N,H,W,C); the model converts at its bounda
 """
 import math
 
-import weakref
-
 import torch
 from torch import nn
 from torch.nn import init
@@ -116,9 +114,6 @@ class GateLayer2d(nn.Module):
         return ops.GateFn.apply(self.conv(x), None, self.act)
 
 
-# id(tensor) -> (weakref to it, (partials, pivot)): BatchNorm statistics a gate kernel already computed for its output
-_bn_handoff = {}
-
 
 class ResidualBlock(nn.Module):
     """lib/nn.py:5-99.  out = gate(f(x)) + x with f one of the recipes 'cabdcabd', 'bacdbac', 'bacdbacd'
@@ -214,18 +209,16 @@ class ResidualBlock(nn.Module):
         # masks are drawn in execution order: conv1's dropout, then conv2's (SURVEY.md §8c noise tape)
         m1, m2 = self._masks(x, noise)
         params = [p for p in self.parameters()]
-        # BatchNorm partials of x, if the previous block's gate kernel produced them for exactly this tensor object
-        ent = _bn_handoff.pop(id(x), None)
-        if ent is not None and ent[0]() is x and self.training:
-            self.__dict__['_in_parts'] = ent[1]
+        # BatchNorm partials of x, if the previous block's gate kernel produced them: they travel as an attribute of exactly that
+        # tensor object (a view, a copy or any other tensor does not carry them)
+        ent = getattr(x, '_lvae_bn_parts', None)
+        if ent is not None and self.training:
+            self.__dict__['_in_parts'] = ent
         out = ops.ResBlockFn.apply(x, self, m1, m2, self.training, *params)
         self.__dict__.pop('_in_parts', None)
         oparts = self.__dict__.pop('_out_parts', None)
         if oparts is not None:
-            if len(_bn_handoff) > 64:
-                for k in [k for k, v in _bn_handoff.items() if v[0]() is None]:
-                    del _bn_handoff[k]
-            _bn_handoff[id(out)] = (weakref.ref(out), oparts)
+            out._lvae_bn_parts = oparts
         if self.training:
             for bn in (self.bn1, self.bn2):
                 if bn is not None:

@@ -51,7 +51,7 @@ def main(argv=None):
         if rank == 0:
             print('data-dependent init: %d convolutions rescaled' % n)
     ldist.broadcast_flat(arena.params)
-    allreduce = ldist.GradAllReduce(arena.grads) if world > 1 else None
+    allreduce = ldist.GradAllReduce(arena.grads, segments=arena.segments) if world > 1 else None
     step_fn = TrainStep(model, opt, beta=1.0, use_graph=not args.no_graph and args.beta_anneal == 0, allreduce=allreduce)
     if rank == 0:
         print(exp.run_description)

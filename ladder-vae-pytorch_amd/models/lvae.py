@@ -108,6 +108,7 @@ class LadderVAE(nn.Module):
 
         self.noise = PhiloxNoise(seed=0)
         self.arena = None
+        self.grad_tracker = None  # dist.GradAllReduce when gradients are exchanged while backward runs (engine.TrainStep sets it)
 
     # ------------------------------------------------------------------------------------------------------------
     # engine plumbing
@@ -128,8 +129,33 @@ class LadderVAE(nn.Module):
         if self.arena is None or not self.arena.owns(first) or first.device != device:
             if first.device != device:
                 super()._apply(lambda t: t.to(device))
-            self.arena = ParamArena(self, device)
+            self.arena = ParamArena(self, device, segment_of=self.grad_segment_of)
         return self.arena
+
+    def grad_segments(self):
+        """Parameter-name prefixes in the order their gradients complete during backward = reverse execution order of forward
+        (forward: stem, bottom_up_layers[0..L-1], top_down_layers[L-1..0], final_top_down, likelihood — models/lvae.py:172-315).
+        The last segment (stem + first block) also takes `top_prior_params`, whose gradient arrives through autograd's own
+        accumulation node rather than from one of our backward launches."""
+        L = self.n_layers
+        return (['likelihood.', 'final_top_down.'] + ['top_down_layers.%d.' % i for i in range(L)] +
+                ['bottom_up_layers.%d.' % i for i in reversed(range(L))] + ['first_bottom_up.'])
+
+    def grad_segment_of(self, name):
+        segs = self.grad_segments()
+        if name.endswith('top_prior_params'):
+            return len(segs) - 1
+        for i, pre in enumerate(segs):
+            if name.startswith(pre):
+                return i
+        raise KeyError(name)
+
+    def _mark(self, x, prefix):
+        """Backward of this identity node runs once every backward launch of segment `prefix` has been issued (x is the segment's
+        input, and every node of the segment is an ancestor of x's gradient); it tells the gradient exchange so."""
+        if self.grad_tracker is None or not torch.is_grad_enabled() or not x.requires_grad:
+            return x
+        return ops.segment_mark(x, self.grad_tracker, self.grad_segments().index(prefix))
 
     def zero_grad(self, set_to_none=False):
         if self.arena is not None:
@@ -169,6 +195,7 @@ class LadderVAE(nn.Module):
         bu_values = self._bottomup(x_pad)
         out, td_data = self._topdown(bu_values)
         out = ops.CropFn.apply(out, tuple(int(s) for s in img_size)) if tuple(out.shape[1:3]) != tuple(img_size) else out
+        out = self._mark(out, 'likelihood.')
         ll, likelihood_info = self.likelihood(out, x_nhwc, self.noise)
 
         kl_ln = ops.StackFn.apply(*td_data['kl'])  # (L, N)
@@ -202,7 +229,7 @@ class LadderVAE(nn.Module):
         x = block(x, self.noise)
         bu_values = []
         for i in range(self.n_layers):
-            x = self.bottom_up_layers[i](x, self.noise)
+            x = self.bottom_up_layers[i](self._mark(x, 'bottom_up_layers.%d.' % i), self.noise)
             bu_values.append(x)
         return bu_values
 
@@ -241,6 +268,10 @@ class LadderVAE(nn.Module):
             fl = forced_latent[i]
             if fl is not None:
                 fl = fl.permute(0, 2, 3, 1).contiguous()
+            if out is not None:
+                out = self._mark(out, 'top_down_layers.%d.' % i)
+            elif bu_value is not None:
+                bu_value = self._mark(bu_value, 'top_down_layers.%d.' % i)
             out, _, aux = self.top_down_layers[i](out, skip_connection_input=out, inference_mode=inference_mode,
                                                   bu_value=bu_value, n_img_prior=n_img_prior, use_mode=i in mode_layers,
                                                   force_constant_output=i in constant_layers, forced_latent=fl,
@@ -249,6 +280,7 @@ class LadderVAE(nn.Module):
             kl[i] = aux['kl_samplewise']
             kl_spatial[i] = aux['kl_spatial']
             logprob_p = logprob_p + aux['logprob_p'].mean()
+        out = self._mark(out, 'final_top_down.')
         for mod in self.final_top_down:
             if isinstance(mod, Placeholder):
                 out = ops.UpsampleFn.apply(out)

@@ -449,6 +449,31 @@ class DmolFn(Function):
         return K.scale_per_sample(dl, _c(g_ll)), None
 
 
+class SegmentMarkFn(Function):
+    """Identity in forward. Its backward runs after every backward node of the model segment that starts at this tensor has been
+    issued: the deferred (grouped) weight gradients of that segment are flushed and the gradient exchange is told the segment's slice
+    of the gradient arena is complete (dist.GradAllReduce.segment_done)."""
+
+    @staticmethod
+    def forward(ctx, x, tracker, seg):
+        ctx.tracker, ctx.seg = tracker, seg
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_wgrad_group()
+        ctx.tracker.segment_done(ctx.seg)
+        return g, None, None
+
+
+def segment_mark(x, tracker, seg):
+    y = SegmentMarkFn.apply(x, tracker, seg)
+    parts = getattr(x, '_lvae_bn_parts', None)   # BatchNorm partials travel with the tensor object (lib/nn.py)
+    if parts is not None:
+        y._lvae_bn_parts = parts
+    return y
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class UpsampleFn(Function):
     @staticmethod

@@ -36,7 +36,23 @@ def _worker(rank, world, port, q):
     mean = g * float(ar.scale)
     want = torch.arange(10007, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
     lo, hi = ldist.shard_batch(64, rank, world)
-    q.put((rank, ok_bcast, nb, bool(torch.allclose(mean, want)), (lo, hi)))
+    # completion-ordered buckets: segments reported during 'backward' trigger their bucket's exchange in order; a segment that is
+    # not the end of a bucket triggers nothing; finish() sends the rest. Every rank must issue the same sequence.
+    segs = [(0, 1000), (1000, 1200), (1200, 5000), (5000, 5100), (5100, 10007)]
+    g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+    ar2 = ldist.GradAllReduce(g2, bucket_mb=4 * 1100 / (1 << 20), segments=segs)   # >= 1100 elements per bucket
+    trace = []
+    ar2.begin_step()
+    for sidx in range(len(segs) - 1):           # the last segment (stem) has no marker: finish() covers it
+        ar2.segment_done(sidx)
+        trace.append(list(ar2.launched))
+    ar2.finish()
+    trace.append(list(ar2.launched))
+    ok_seg = bool(torch.allclose(g2 * float(ar2.scale), want))
+    # evaluation reduction over ranks (evaluate.py:86-87 restated): per-rank sums of the per-image bounds, one all-reduce
+    from lvae_amd.evaluate import reduce_eval_sums
+    tot = reduce_eval_sums(torch.tensor([10.0 * (rank + 1), -3.0 * (rank + 1), 4.0 + rank], dtype=torch.float64))
+    q.put((rank, ok_bcast, nb, bool(torch.allclose(mean, want)), (lo, hi), ar2.buckets, trace, ok_seg, tot.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +74,11 @@ def test_world_size_2_gloo_allreduce_and_sharding():
     assert all(r[2] == 4 for r in res)
     assert all(r[3] for r in res), 'bucketed all-reduce * 1/world != mean gradient'
     assert res[0][4] == (0, 32) and res[1][4] == (32, 64)
+    for r in res:
+        assert r[5] == [(0, 1200, 1), (1200, 5000, 2), (5000, 10007, 4)], r[5]
+        assert r[6] == [[], [0], [0, 1], [0, 1], [0, 1, 2]], r[6]
+        assert r[7], 'segment-ordered exchange != mean gradient'
+        assert r[8] == [30.0, -9.0, 9.0]
 
 
 def test_bucket_slices_cover_exactly():
@@ -70,3 +91,34 @@ def test_bucket_slices_cover_exactly():
     import pytest
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def test_arena_is_laid_out_in_gradient_completion_order():
+    """models/lvae.py:74,87-88,156,159-167 registers bottom-up / top-down layers interleaved; the gradient arena must instead follow
+    reverse execution order so that data-parallel buckets are contiguous and complete early (dist.GradAllReduce)."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd.arena import ParamArena
+    from lvae_amd.dist import make_buckets
+    from lvae_amd.models.lvae import LadderVAE
+    from conftest import load_golden
+    cfg = dict(load_golden('tiny_cifar').cfg)
+    cfg['learn_top_prior'] = True
+    m = LadderVAE(**cfg)
+    reg_order = [k for k, _ in m.named_parameters()]
+    arena = ParamArena(m, torch.device('cpu'), segment_of=m.grad_segment_of)
+    segs = m.grad_segments()
+    assert segs[0] == 'likelihood.' and segs[1] == 'final_top_down.' and segs[2] == 'top_down_layers.0.' and segs[-1] == 'first_bottom_up.'
+    ids = [m.grad_segment_of(k) for k in arena.names[:len([p for p in m.parameters() if p.requires_grad])]]
+    assert ids == sorted(ids) and set(ids) == set(range(len(segs)))
+    assert m.grad_segment_of('top_down_layers.2.top_prior_params') == len(segs) - 1      # arrives via autograd accumulation: last
+    assert len(arena.segments) == len(segs) and arena.segments[0][0] == 0 and arena.segments[-1][1] == arena.n_train
+    assert all(a[1] == b[0] for a, b in zip(arena.segments, arena.segments[1:]))
+    # slots still address every parameter; values survived the permutation; state_dict order is the registration order
+    assert list(k for k, _ in m.named_parameters()) == reg_order
+    for k, p in m.named_parameters():
+        off, n = arena.slots[k]
+        assert p.numel() == n and p.data_ptr() == arena.params.data_ptr() + 4 * off
+    bk = make_buckets(arena.segments, 1)
+    assert len(bk) == len(segs) and [b[2] for b in bk] == list(range(len(segs)))
+    bk = make_buckets(arena.segments, arena.n_train)
+    assert bk == [(0, arena.n_train, len(segs) - 1)]

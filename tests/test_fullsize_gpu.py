@@ -121,10 +121,11 @@ def run_engine(case, use_graph):
 @pytest.mark.parametrize('case', list(CASES))
 def test_full_training_step_matches_oracle(case, use_graph):
     rec = run_engine(case, use_graph)
-    # stated fp32 tolerances: scalars 1e-5 relative (BASELINE asks 1e-3), per-layer KL 1e-4 rel + 1e-4,
-    # per-tensor gradient relative L2 5e-4, global gradient norm 1e-4
+    # SURVEY.md §8(c) fp32 tolerances, unloosened: loss / elbo relative 1e-5 (BASELINE asks 1e-3), per-layer KL 1e-5 relative
+    # (+1e-4 absolute), per-tensor gradient relative L2 1e-4; the global gradient norm to 1e-6.
+    # Measured on MI355X (profiles/r02_fullsize_parity.json): scalars <= 1.7e-7, per-layer KL <= 6e-7, worst tensor 9.1e-6, norm 3e-8.
     for k in ('loss', 'elbo', 'recons', 'kl', 'l2'):
         assert rec[k]['rel'] <= 1e-5, (k, rec[k])
-    assert rec['kl_layer_max_rel'] <= 1e-4 or rec['kl_layer_max_abs'] <= 1e-4, rec
-    assert rec['grad_worst_rel_l2'] <= 5e-4, (rec['grad_worst_key'], rec['grad_worst_rel_l2'])
-    assert rec['gradnorm']['rel'] <= 1e-4, rec['gradnorm']
+    assert rec['kl_layer_max_rel'] <= 1e-5 or rec['kl_layer_max_abs'] <= 1e-4, rec
+    assert rec['grad_worst_rel_l2'] <= 1e-4, (rec['grad_worst_key'], rec['grad_worst_rel_l2'])
+    assert rec['gradnorm']['rel'] <= 1e-6, rec['gradnorm']

@@ -466,9 +466,19 @@ def test_likelihood_golden_vectors(K):
     # DMoL log-likelihood, gradient and sampler against the reference's outputs
     l, xd = g.t('dmol.l'), g.t('dmol.x')
     ll, dl = K.dmol_ll_fwd(nhwc(l), nhwc(xd), True)
-    torch.testing.assert_close(ll.cpu(), g.t('dmol.ll'), rtol=1e-5, atol=1e-3)
-    # the stress vector sits where cdf_delta ~ 1e-5: the reference's own fp32 gradient is only good to ~1e-2 there
-    torch.testing.assert_close(nchw(dl), g.t('dmol.dl'), rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(ll.cpu(), g.t('dmol.ll'), rtol=1e-5, atol=1e-4)
+    # Gradient: this stress vector sits where cdf_delta ~ 1e-5 (sigmoid(plus) - sigmoid(min) cancels to 2-3 digits in fp32), so the
+    # REFERENCE's own fp32 gradient is only good to ~1e-2 there. Measured, not assumed: the same formula in float64 is the
+    # yardstick; the kernel must be at least as close to it as the reference's fp32 result is (and close to the reference within
+    # the reference's own error).
+    from oracle import lvae_ref as R
+    l64 = l.double().requires_grad_(True)
+    R.discretized_mix_logistic_ll(xd.double() * 2 - 1, l64).sum().backward()
+    ref_err = float((g.t('dmol.dl').double() - l64.grad).abs().max())
+    our_err = float((nchw(dl).double() - l64.grad).abs().max())
+    assert ref_err > 1e-4, ref_err            # the vector really is ill-conditioned in fp32
+    assert our_err <= 2.0 * ref_err + 1e-5, (our_err, ref_err)
+    torch.testing.assert_close(nchw(dl), g.t('dmol.dl'), rtol=1e-4, atol=3.0 * ref_err)
     tape = g.seq('dmol.tape')
     s = K.dmol_sample(nhwc(l), tape[0].cuda().contiguous(), tape[1].cuda().contiguous())
     torch.testing.assert_close(nchw(s) * 2 - 1, g.t('dmol.sample'), rtol=1e-5, atol=1e-5)
