@@ -181,7 +181,7 @@ def main():
     opt = Adamax(model, lr=3e-4)
     allreduce = (ldist.GradAllReduce(arena.grads, segments=arena.segments)
                  if (world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1') else None)
-    if world > max(1, torch.cuda.device_count()) and not args.no_graph:
+    if world > max(1, torch.cuda.device_count()) and not args.no_graph and os.environ.get('LVAE_ALLOW_GLOO_GRAPH') != '1':
         # rehearsal with several ranks on ONE device: two processes replaying multi-thousand-node graphs on one GPU time-slice
         # through compute-wave save/restore (seconds per step, gpurun_out/ddp2g.log of round 1); launch eagerly instead
         log('ranks share a device: hipGraph replay disabled')

@@ -7,6 +7,10 @@ all-reduce is part of the same graph: each bucket of the (completion-ordered) gr
 soon as backward has left it (dist.GradAllReduce), and Adamax waits for the last one. LVAE_DDP_MODE=split keeps the exchange
 outside the graphs instead (fwd+bwd graph | eager all-reduce | Adamax graph): collectives that are not captured.
 """
+import os
+import sys
+import time
+
 import torch
 
 from . import kernels as K
@@ -52,8 +56,10 @@ class TrainStep:
         if allreduce is not None and allreduce.world > 1:
             optimizer._state()
             optimizer.gscale = allreduce.scale
-        if allreduce is not None and allreduce.active and allreduce.on_gpu and not allreduce.capturable:
+        if (allreduce is not None and allreduce.active and allreduce.on_gpu and not allreduce.capturable
+                and os.environ.get('LVAE_ALLOW_GLOO_GRAPH') != '1'):   # (the override exists for the stall diagnosis of DESIGN.md §6)
             self.use_graph, self.eager_left = False, -1   # gloo stages device buffers through the host: cannot be part of a graph
+        self.trace = os.environ.get('LVAE_STEP_TRACE') == '1'   # diagnosis only: host-synchronised phase times on stderr
         self.overlap = allreduce is not None and allreduce.active and allreduce.overlap
         if self.overlap:
             model.grad_tracker = allreduce   # the model's segment markers report to it during backward
@@ -104,6 +110,17 @@ class TrainStep:
                 self.opt.step()
         self._bns = self.model.bn_modules()
 
+    def _traced_split_step(self):
+        ts = [time.perf_counter()]
+        for phase in (self.graph_a.replay, self.allreduce.run, self.graph_b.replay):
+            phase()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter())
+        print('[step-trace] graph A %.1f ms | all-reduce %.1f ms | graph B %.1f ms' %
+              tuple((b - a) * 1e3 for a, b in zip(ts, ts[1:])), file=sys.stderr, flush=True)
+        K.prepared.weights_written()
+        return self.static_out
+
     def __call__(self, x):
         self.model.global_step += 1
         if not self.use_graph or self.eager_left > 0:
@@ -114,6 +131,8 @@ class TrainStep:
             self._capture(x)  # the Python forward ran once while capturing: it already counted this step's BN forwards
         else:
             self.static_x.copy_(x, non_blocking=True)
+        if self.trace and self.graph_b is not None:
+            return self._traced_split_step()
         self.graph_a.replay()
         if self.graph_b is not None:
             self.allreduce.run()
