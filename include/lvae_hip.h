@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 5
+#define LVAE_ABI_VERSION 6
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -64,6 +64,24 @@ const char* lvae_last_error(void);
  *           lib/nn.py:89 fused into out_scale, torch.cat of models/lvae_layers.py:359 fused as (x, x2), and the
  *           autograd dgrad of all of them (same kernel, transposed weight strides, other gather).
  * ---------------------------------------------------------------------------------------------------------- */
+/* Folded BatchNorm finalize of a convolution INPUT (training mode, nn.BatchNorm2d of lib/nn.py:80-81): instead of in_scale /
+ * in_shift the kernel gets the partial sums the producer's statistics epilogue wrote — parts [rows + 1][2][C1], whose LAST row
+ * holds that producer's pivot (kernels for which lvae_conv2d_folds_bn_finalize != 0, and the gate kernel, store it) — computes
+ * scale / shift in its prologue (M = N*H*W elements per channel; gamma / beta may be NULL = 1 / 0), publishes (scale, shift,
+ * mean, rstd) to coef_out [4][C1] for the backward and applies the momentum update to running_mean / running_var (may be NULL).
+ * Only for descriptors with lvae_conv2d_folds_bn_finalize(d) != 0. */
+typedef struct lvae_bn_fold {
+  const float* parts;
+  int32_t rows;
+  int64_t M;
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  float* coef_out;
+} lvae_bn_fold;
+
 typedef struct lvae_conv_desc {
   const float* x;        /* [N,H,W,C1] */
   const float* x2;       /* [N,H,W,C2] or NULL: channels C1..C1+C2 of the logical input */
@@ -94,6 +112,8 @@ typedef struct lvae_conv_desc {
   int32_t stats_mode;     /* LVAE_STATS_BN_FWD (0, the default) or LVAE_STATS_BN_BWD */
   int32_t stats_act;      /* activation of that BatchNorm block (mode LVAE_STATS_BN_BWD) */
   const float* stats_x;
+  /* Folded BatchNorm finalize of the INPUT: NULL, or a HOST pointer to the block below (read by the launcher, not by the device) */
+  const struct lvae_bn_fold* in_fold;
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -106,6 +126,9 @@ int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
  * leave stats_out NULL and use lvae_bn_stats_f32 on y). Set workspace / workspace_bytes before asking: the answer depends on
  * the variant. */
 int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d);
+/* 1 when the variant selected for `d` also stores its pivot behind the partial rows (stats_out then needs rows + 1 rows) and can
+ * itself consume such a buffer through d->in_parts (the position-major kernel of the <= 4x4 levels); 0 otherwise. */
+int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d);
 
 /* Batched weight pre-transform: one launch for every convolution of a training step instead of one per convolution call.
  * For each descriptor with lvae_conv2d_workspace(d) > 0 give it a PRIVATE scratch buffer in d->workspace (kept until the
@@ -123,8 +146,9 @@ int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32_t max_cout
  * lvae_gate_fwd_f32 instead). */
 int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, int32_t act, float* out, void* stream);
 /* With d->stats_out / d->stats_pivot ([C] pivot) set, lvae_conv1x1_gate_f32 also writes BatchNorm partials of `out` — the next
- * residual block's BatchNorm input — as [lvae_conv1x1_gate_stats_rows(d)][2][C] for lvae_bn_finalize_parts_f32 (0 rows: not
- * supported for this shape, leave stats_out NULL). */
+ * residual block's BatchNorm input — as [lvae_conv1x1_gate_stats_rows(d) + 1][2][C]: the partial rows for
+ * lvae_bn_finalize_parts_f32 / lvae_bn_fold, then one row whose first C floats are the pivot (0 rows: not supported for this
+ * shape, leave stats_out NULL). */
 int32_t lvae_conv1x1_gate_stats_rows(const lvae_conv_desc* d);
 /* GateLayer2d backward fused with the dgrad of its 1x1 convolution (autograd of lib/nn.py:118-126): forms
  *   dab[m,c] = dout*sigmoid(b)*act'(a) ; dab[m,C+c] = dout*act(a)*sigmoid(b)*(1-sigmoid(b))      (a, b = the halves of ab)

@@ -30,10 +30,18 @@ class ConvDesc(C.Structure):
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
         ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p), ('stats_mode', C.c_int32), ('stats_act', C.c_int32),
         ('stats_x', C.c_void_p),
+        ('in_fold', C.c_void_p),
     ]
 
 
-ABI_VERSION = 5  # LVAE_ABI_VERSION of include/lvae_hip.h
+class BnFold(C.Structure):
+    """mirror of struct lvae_bn_fold"""
+    _fields_ = [('parts', C.c_void_p), ('rows', C.c_int32), ('M', C.c_int64), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('eps', C.c_float), ('momentum', C.c_float), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('coef_out', C.c_void_p)]
+
+
+ABI_VERSION = 6  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -44,6 +52,7 @@ SIGNATURES = {
     'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_stats_rows': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_conv2d_folds_bn_finalize': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_prepare_entry_bytes': (_Z, []),
     'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_prepare_weights': (C.c_int, [_P, _I, _I, _P]),

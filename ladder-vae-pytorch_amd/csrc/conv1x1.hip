@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
         float v = 0.f;
         for (int r = 0; r < G; ++r) v += red[which * G * C + r * C + c];
         d.stats_out[((size_t)blockIdx.x * 2 + which) * C + c] = v;
+        // the pivot travels with the partials (row gridDim.x): a consumer that finalizes them in its own prologue (lvae_bn_fold) must
+        // not depend on a buffer it updates itself
+        if (blockIdx.x == 0 && which == 0) d.stats_out[((size_t)gridDim.x * 2) * C + c] = d.stats_pivot[c];
       }
     }
   } else {

@@ -353,6 +353,9 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
   return 0;
 }
 
+int conv3x3_pos_try(const lvae_conv_desc* d, hipStream_t s);
+int conv3x3_pos_stats_rows(const lvae_conv_desc* d);
+bool conv3x3_pos_eligible(const lvae_conv_desc* d);
 int conv3x3_halo_try(const lvae_conv_desc* d, hipStream_t s);
 int conv3x3_halo_stats_rows(const lvae_conv_desc* d);
 int conv3x3_wino_stats_rows(const lvae_conv_desc* d);
@@ -376,10 +379,17 @@ extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
 
 extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
   if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
+  const int p = conv3x3_pos_stats_rows(d);
+  if (p > 0) return p;
   const int w = conv3x3_wino_stats_rows(d);
   if (w > 0) return w;
   if (d->workspace != nullptr && conv3x3_wino_eligible(d) && (size_t)d->workspace_bytes >= conv3x3_wino_workspace(d)) return 0;
   return conv3x3_halo_stats_rows(d);
+}
+
+extern "C" int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d) {
+  if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
+  return conv3x3_pos_eligible(d) ? 1 : 0;
 }
 
 extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
@@ -392,8 +402,13 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
                    (d->stats_mode == LVAE_STATS_BN_BWD && d->stats_x != nullptr && (reinterpret_cast<uintptr_t>(d->stats_x) & 15) == 0),
                LVAE_EINVAL, "lvae_conv2d_f32: bad stats_mode / stats_x");
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
+  LVAE_REQUIRE(d->in_fold == nullptr || (!halo_off && conv3x3_pos_eligible(d) && d->in_fold->parts != nullptr &&
+                                          d->in_fold->rows > 0 && d->in_fold->M > 0 && d->in_scale == nullptr),
+               LVAE_EINVAL, "lvae_conv2d_f32: in_fold set but lvae_conv2d_folds_bn_finalize(d) == 0 (or bad parts / rows / M, or in_scale given too)");
   if (!halo_off) {
-    int hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);
+    int hr = conv3x3_pos_try(d, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+    hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);
     if (hr != -1000) return hr;
     hr = conv3x3_halo_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;

@@ -10,7 +10,7 @@ import weakref
 import torch
 
 from . import _C
-from ._C import ACT, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, call, ptr, stream_ptr
+from ._C import ACT, BnFold, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, call, ptr, stream_ptr
 
 _ws_cache = {}
 
@@ -195,12 +195,30 @@ def _ddi_conv(state, x, weight, g, bias, x2, in_scale, in_shift, in_act, out_sca
     return y
 
 
+class StatParts:
+    """BatchNorm partial sums a kernel epilogue wrote for its OUTPUT: buf (rows [+1], 2, C) — (sum(y - pivot), sum((y - pivot)^2)) per
+    workgroup row; has_pivot: the producer stored its pivot in row `rows` (such a buffer can be finalized inside the consuming
+    convolution's prologue, see lvae_bn_fold)."""
+    __slots__ = ('buf', 'rows', 'has_pivot')
+
+    def __init__(self, buf, rows, has_pivot):
+        self.buf, self.rows, self.has_pivot = buf, rows, has_pivot
+
+    def rows_view(self):
+        return self.buf[:self.rows]
+
+
 def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None,
-           stats_pivot=None):
+           stats_pivot=None, in_bn=None):
     """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC.
     stats_pivot (Cout,): also ask the kernel's epilogue for BatchNorm partials of y around that pivot; returns (y, parts) with
-    parts (rows, 2, Cout) for bn_finalize_parts, or (y, None) when the kernel variant chosen for this shape has no such epilogue."""
+    parts a StatParts, or (y, None) when the kernel variant chosen for this shape has no such epilogue.
+    in_bn = (parts: StatParts, pivot, bn): training-mode BatchNorm of the INPUT whose statistics exist as partial sums (bn has
+    weight, bias, running_mean, running_var, eps, momentum); the coefficients are finalized inside the convolution when the
+    selected kernel can do that (lvae_conv2d_folds_bn_finalize) and by lvae_bn_finalize_parts_f32 otherwise. Returns
+    (y, parts | None, (scale, shift, mean, rstd))."""
     if _ddi is not None and weight.data_ptr() not in _ddi['done']:
+        assert in_bn is None
         y = _ddi_conv(_ddi, x, weight, g, bias, x2, in_scale, in_shift, in_act, out_scale, out_act)
         return y if stats_pivot is None else (y, None)
     _chk_nhwc(x, 'x')
@@ -215,13 +233,32 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
     _conv_ws(d, weight, x.device)
+    lib = _C.load()
+    coef = fold = None
+    if in_bn is not None:
+        sp, pivot, bn = in_bn
+        M = N * H * W
+        if sp.has_pivot and x2 is None and lib.lvae_conv2d_folds_bn_finalize(C.byref(d)):
+            coef = torch.empty((4, C1), dtype=torch.float32, device=x.device)
+            fold = BnFold(ptr(sp.buf), sp.rows, M, ptr(bn.weight), ptr(bn.bias), bn.eps, bn.momentum, ptr(bn.running_mean),
+                          ptr(bn.running_var), ptr(coef))
+            d.in_fold = C.addressof(fold)
+            coef = (coef[0], coef[1], coef[2], coef[3])
+        else:
+            coef = bn_finalize_parts(sp.rows_view(), M, pivot, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            d.in_scale, d.in_shift = ptr(coef[0]), ptr(coef[1])
     parts = None
     if stats_pivot is not None:
-        rows = _C.load().lvae_conv2d_stats_rows(C.byref(d))
+        rows = lib.lvae_conv2d_stats_rows(C.byref(d))
         if rows > 0:
-            parts = torch.empty((rows, 2, g.Cout), dtype=torch.float32, device=x.device)
-            d.stats_out, d.stats_pivot = ptr(parts), ptr(stats_pivot)
+            piv_row = bool(lib.lvae_conv2d_folds_bn_finalize(C.byref(d)))
+            buf = torch.empty((rows + int(piv_row), 2, g.Cout), dtype=torch.float32, device=x.device)
+            parts = StatParts(buf, rows, piv_row)
+            d.stats_out, d.stats_pivot = ptr(buf), ptr(stats_pivot)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
+    del fold
+    if in_bn is not None:
+        return y, parts, coef
     return y if stats_pivot is None else (y, parts)
 
 
@@ -246,8 +283,9 @@ def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True, stats_pivot=None):
     if stats_pivot is not None:
         rows = _C.load().lvae_conv1x1_gate_stats_rows(C.byref(d))
         if rows > 0:
-            parts = torch.empty((rows, 2, Cn), dtype=torch.float32, device=x.device)
-            d.stats_out, d.stats_pivot = ptr(parts), ptr(stats_pivot)
+            buf = torch.empty((rows + 1, 2, Cn), dtype=torch.float32, device=x.device)   # last row: the pivot (written by the kernel)
+            parts = StatParts(buf, rows, True)
+            d.stats_out, d.stats_pivot = ptr(buf), ptr(stats_pivot)
     call('lvae_conv1x1_gate_f32', C.byref(d), ptr(res), ACT[act], ptr(out), stream_ptr())
     return (ab, out) if stats_pivot is None else (ab, out, parts)
 

@@ -171,25 +171,29 @@ class ResBlockFn(Function):
         # kernel (handed over through blk._in_parts by lib/nn.py), for conv1's output by conv1 itself
         parts, pivot_in = blk.__dict__.pop('_in_parts', None) or (None, None)
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
-            if bn is not None:
-                if training and parts is not None:
-                    sc, sh, mean, rstd = K.bn_finalize_parts(parts, h.numel() // h.shape[3], pivot_in if i == 0 else bn.running_mean,
-                                                             bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
-                elif training:
-                    sc, sh, mean, rstd = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                                    bn.momentum)
-                else:
-                    sc, sh = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-                    mean = rstd = None
-            else:
-                sc, sh = _ones_zeros(C, dev)
-                mean = rstd = None
             nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
-            if training and nxt is not None and nxt.running_mean is not None:
-                y, parts = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m,
-                                    stats_pivot=nxt.running_mean)
+            want_stats = training and nxt is not None and nxt.running_mean is not None
+            if bn is not None and training and parts is not None:
+                # statistics of h exist as partial sums: finalized inside the convolution where the kernel can (<= 4x4 levels)
+                y, parts_out, (sc, sh, mean, rstd) = K.conv2d(
+                    h, cv.weight, cv.geom(), bias=cv.bias, in_act=act, out_scale=m, in_bn=(parts, pivot_in if i == 0 else bn.running_mean, bn),
+                    stats_pivot=nxt.running_mean if want_stats else None)
             else:
-                y, parts = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m), None
+                if bn is not None:
+                    if training:
+                        sc, sh, mean, rstd = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+                    else:
+                        sc, sh = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+                        mean = rstd = None
+                else:
+                    sc, sh = _ones_zeros(C, dev)
+                    mean = rstd = None
+                if want_stats:
+                    y, parts_out = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m,
+                                            stats_pivot=nxt.running_mean)
+                else:
+                    y, parts_out = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m), None
+            parts = parts_out
             st.append((h, sc, sh, mean, rstd))
             h = y
         y2 = h

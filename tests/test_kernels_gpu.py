@@ -348,7 +348,7 @@ def test_bn_statistics_from_conv_epilogue(K, case):
     geom = K.ConvGeom(wp, 1, 1)
     y, parts = K.conv2d(x, wp, geom, bias=b, out_scale=drop, stats_pivot=rm)
     assert parts is not None, "this shape is meant to take a kernel with the statistics epilogue"
-    got = K.bn_finalize_parts(parts, N * H * W, rm, gamma, beta, rm, rv)
+    got = K.bn_finalize_parts(parts.rows_view(), N * H * W, rm, gamma, beta, rm, rv)
     ref = K.bn_stats(y, gamma, beta, rm2, rv2)
     for a_, b_ in zip(got, ref):
         torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
@@ -371,7 +371,8 @@ def test_bn_statistics_from_gate_epilogue(K, shape):
     pivot = torch.randn(C, generator=g).cuda()
     ab, out, parts = K.conv1x1_gate(x, wp, K.ConvGeom(wp, 1, 0), b, res, 'elu', stats_pivot=pivot)
     assert parts is not None
-    got = K.bn_finalize_parts(parts, N * H * W, pivot, gamma, beta, rm, rv)
+    assert parts.has_pivot and torch.equal(parts.buf[parts.rows, 0], pivot)      # the pivot travels behind the partial rows
+    got = K.bn_finalize_parts(parts.rows_view(), N * H * W, pivot, gamma, beta, rm, rv)
     ref = K.bn_stats(out, gamma, beta, rm2, rv2)
     for a_, b_ in zip(got, ref):
         torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
@@ -566,3 +567,71 @@ def test_rng_statistics(K):
     K.counter_advance(off)
     a3 = K.rng_fill(torch.empty(n, device='cuda'), 'normal', 0, 0, 1234, off, 1)
     assert abs(float((a * a3).mean())) < 5e-3  # next step: fresh, uncorrelated
+
+
+POS_CASES = [
+    # N, Cin, Cout, H, W
+    (256, 64, 64, 4, 4), (256, 64, 64, 2, 2), (37, 64, 64, 4, 4), (5, 32, 64, 2, 2), (70, 64, 64, 3, 4), (33, 64, 100, 1, 1),
+    (64, 64, 32, 4, 2),
+]
+
+
+@pytest.mark.parametrize('case', POS_CASES)
+def test_conv3x3_position_major_small_images(K, case):
+    """Low-resolution levels (H*W <= 16): the position-major kernel — forward and dgrad with fused BN+ELU prologue, bias, dropout
+    scale, statistics epilogues — against torch's direct convolution (lib/nn.py:83-89 call sites)."""
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    sc, sh = 1 + 0.1 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+    drop = (torch.rand(N, Co, generator=g) < 0.8).float() / 0.8
+    piv = 0.05 * torch.randn(Co, generator=g)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    ref = F.conv2d(F.elu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), w, b, padding=1) * drop.view(N, Co, 1, 1)
+    y, parts = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu', out_scale=drop.cuda(),
+                        stats_pivot=piv.cuda())
+    assert parts is not None and parts.has_pivot and parts.rows == ((N + 31) // 32) * H * W     # the position-major kernel ran
+    assert rel(nchw(y), ref) < 2e-6
+    s = parts.rows_view().sum(0).cpu().double()
+    dl = (ref.double() - piv.double().view(1, -1, 1, 1))
+    torch.testing.assert_close(s[0], dl.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(s[1], (dl * dl).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.equal(parts.buf[parts.rows, 0].cpu(), piv)
+    # dgrad (transposed gather, k-contiguous weights) with the Dropout2d scale of the producer
+    dy = torch.randn(N, Co, H, W, generator=g)
+    dref = F.conv_transpose2d(dy, w, padding=1)
+    dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W))
+    assert rel(nchw(dx), dref) < 2e-6
+
+
+@pytest.mark.parametrize('case', [(256, 64, 4, 4), (96, 64, 2, 2), (40, 32, 4, 4)])
+def test_bn_finalize_folded_into_the_consuming_convolution(K, case):
+    """lvae_bn_fold: conv1 writes BatchNorm partials (+ its pivot) of its output; conv2 finalizes them in its prologue, publishes
+    (scale, shift, mean, rstd) and updates the running statistics — against nn.BatchNorm2d semantics (lib/nn.py:80-81)."""
+    import types
+    N, Cc, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w1 = torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)
+    w2 = torch.randn(64, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    rm0, rv0 = 0.1 * torch.randn(Cc, generator=g), 1 + 0.2 * torch.rand(Cc, generator=g)
+    wp1, wp2 = packed_weight(w1), packed_weight(w2)
+    g1, g2 = K.ConvGeom(wp1, 1, 1), K.ConvGeom(wp2, 1, 1)
+    bn = types.SimpleNamespace(weight=gamma.cuda(), bias=beta.cuda(), running_mean=rm0.cuda(), running_var=rv0.cuda(), eps=1e-5, momentum=0.1)
+    y1, parts = K.conv2d(nhwc(x), wp1, g1, stats_pivot=bn.running_mean)
+    assert parts is not None and parts.has_pivot
+    y2, _, (sc, sh, mean, rstd) = K.conv2d(y1, wp2, g2, in_act='elu', in_bn=(parts, bn.running_mean, bn))
+    r1 = F.conv2d(x, w1, None, padding=1)
+    rmr, rvr = rm0.clone(), rv0.clone()
+    h = F.batch_norm(r1, rmr, rvr, gamma, beta, True, 0.1, 1e-5)
+    r2 = F.conv2d(F.elu(h), w2, None, padding=1)
+    assert rel(nchw(y2), r2) < 5e-6
+    torch.testing.assert_close(mean.cpu(), r1.mean((0, 2, 3)), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd.cpu(), 1 / torch.sqrt(r1.var((0, 2, 3), unbiased=False) + 1e-5), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sc.cpu(), gamma * rstd.cpu(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(bn.running_mean.cpu(), rmr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var.cpu(), rvr, rtol=1e-5, atol=1e-6)
