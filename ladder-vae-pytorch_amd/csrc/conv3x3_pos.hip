@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
   constexpr int BPT = CIN_T * 32 / 4 / 256;  // float4 of a weight tap per thread (2 / 1)
   constexpr int KW_ = CIN_T / 4;             // reduction channels per wave (16 / 8)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float s_fin[8 * 2 * 32 + 2 * 64];  // finalize scratch [parts][2][C] (C*parts = 256) + scale[64] + shift[64]
+  __shared__ float s_fin[4 * 2 * 64 + 2 * 64];  // finalize scratch [4 row groups][2][64] + scale[64] + shift[64]
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
 
@@ -93,22 +93,24 @@ __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
   const lvae_bn_fold& f = a.f;
   const bool has_tf = f.parts != nullptr || d.in_scale != nullptr;
   if (f.parts != nullptr) {
-    const int C = Cin, G = 256 / C;  // C in {32, 64} on this path (checked on the host): G row groups
-    const int c = t % C, g = t / C;
+    constexpr int G = 4;  // row groups: thread -> (channel t & 63, rows g, g + 4, ...); C <= 64 on this path
+    const int C = Cin;
+    const int c = t & 63, g = t >> 6;
     const int rows = f.rows;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = g; r < rows; r += G) {
-      s1 += f.parts[((size_t)r * 2) * C + c];
-      s2 += f.parts[((size_t)r * 2 + 1) * C + c];
-    }
-    s_fin[(g * 2) * C + c] = s1;
-    s_fin[(g * 2 + 1) * C + c] = s2;
+    if (c < C)
+      for (int r = g; r < rows; r += G) {
+        s1 += f.parts[((size_t)r * 2) * C + c];
+        s2 += f.parts[((size_t)r * 2 + 1) * C + c];
+      }
+    s_fin[(g * 2) * 64 + c] = s1;
+    s_fin[(g * 2 + 1) * 64 + c] = s2;
     __syncthreads();
     if (t < C) {
       double sa = 0.0, sb = 0.0;
       for (int q = 0; q < G; ++q) {
-        sa += (double)s_fin[(q * 2) * C + t];
-        sb += (double)s_fin[(q * 2 + 1) * C + t];
+        sa += (double)s_fin[(q * 2) * 64 + t];
+        sb += (double)s_fin[(q * 2 + 1) * 64 + t];
       }
       const float pivot = f.parts[((size_t)rows * 2) * C + t];  // the producer's pivot, stored behind its partial rows
       const double M = (double)f.M, inv_m = 1.0 / M, dm = sa * inv_m;
@@ -281,7 +283,6 @@ static bool pos_select(const lvae_conv_desc* d, bool& ncontig) {
     return false;
   const bool kc = d->w_sk == 1 && d->w_sn % 4 == 0, nc = d->w_sn == 1 && d->w_sk % 4 == 0;
   if (!kc && !nc) return false;
-  if (d->in_fold != nullptr && (Cin != 32 && Cin != 64)) return false;
   ncontig = nc;
   return true;
 }
