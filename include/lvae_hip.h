@@ -16,7 +16,8 @@
  *    kernel (an idempotent hipFuncSetAttribute on first use). Read-only process state: the tuning / A-B switches below, each read
  *    from the environment once on first use; every value selects among kernel variants that pass the same parity tests:
  *      LVAE_DISABLE_WINO, LVAE_DISABLE_WINO_WGRAD, LVAE_DISABLE_HALO, LVAE_DISABLE_W1X1   (fall back to the direct kernels)
- *      LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
+ *      LVAE_F32_SPLIT (0: keep the large fp32 3x3 layers on the fp32 MFMA instead of the six-product bf16 split), LVAE_DISABLE_POS,
+ *      LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
  *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
  *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
  *    caller owns (ladder-vae-pytorch_amd/dist.py). SURVEY.md §8(b) sketched lvae_allreduce_{init,enqueue,wait,destroy}; they
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 6
+#define LVAE_ABI_VERSION 7
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -41,6 +42,7 @@ extern "C" {
 
 /* activation ids shared by every kernel (models/lvae.py:64-69 nonlin table) */
 enum { LVAE_STATS_BN_FWD = 0, LVAE_STATS_BN_BWD = 1 };
+enum { LVAE_PREC_F32 = 0, LVAE_PREC_BF16 = 1 };
 enum { LVAE_ACT_NONE = 0, LVAE_ACT_ELU = 1, LVAE_ACT_RELU = 2, LVAE_ACT_LEAKYRELU = 3, LVAE_ACT_SELU = 4 };
 
 /* spatial gather of an implicit-GEMM convolution */
@@ -98,6 +100,9 @@ typedef struct lvae_conv_desc {
   int32_t N, H, W, OH, OW, Cout;
   int32_t KH, KW, stride, pad;
   int32_t gather;        /* LVAE_GATHER_* */
+  int32_t precision;     /* LVAE_PREC_F32 (0): results as an fp32 multiply-add chain (fp32 MFMA, Winograd, or six exact bf16-piece
+                            products per fp32 product); LVAE_PREC_BF16: operands rounded to bf16 at the matrix-core input, fp32
+                            accumulate (kernel variants that have no bf16 form run in fp32) */
   void* workspace;       /* scratch for lvae_conv2d_f32 (transformed weights of the Winograd path) or NULL */
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
   int32_t workspace_ready; /* non-zero: `workspace` already holds this descriptor's transformed weights (written by
@@ -121,6 +126,11 @@ typedef struct lvae_conv_desc {
  * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
 size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+/* The same convolution with bf16 matrix-core operands (v_mfma_f32_32x32x16_bf16): activations (after the fused input transform)
+ * and weights are rounded to bf16, products are exact, accumulation, bias, statistics and the stored result are fp32 — the
+ * arithmetic of the reference's nn.Conv2d call sites under torch.autocast(bfloat16) (BASELINE configs[1], [3], [4]). Equivalent to
+ * lvae_conv2d_f32 on a descriptor with precision = LVAE_PREC_BF16. Set precision before asking lvae_conv2d_stats_rows. */
+int lvae_conv2d_bf16(const lvae_conv_desc* d, void* stream);
 /* BatchNorm statistics of the convolution OUTPUT fused into the producing kernel's epilogue (saves the separate pass over y):
  * rows of d->stats_out the launch will write, or 0 when the kernel variant this descriptor selects cannot produce them (then
  * leave stats_out NULL and use lvae_bn_stats_f32 on y). Set workspace / workspace_bytes before asking: the answer depends on

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
 
 ACT = {None: 0, 'none': 0, 'elu': 1, 'relu': 2, 'leakyrelu': 3, 'selu': 4}
 GATHER_CONV, GATHER_TRANSPOSED = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
 
 
 class LvaeHipError(RuntimeError):
@@ -28,7 +29,7 @@ class ConvDesc(C.Structure):
         ('out_scale', C.c_void_p), ('out_act', C.c_int32), ('y', C.c_void_p),
         ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
         ('Cout', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-        ('gather', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p), ('stats_mode', C.c_int32), ('stats_act', C.c_int32),
+        ('gather', C.c_int32), ('precision', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p), ('stats_mode', C.c_int32), ('stats_act', C.c_int32),
         ('stats_x', C.c_void_p),
         ('in_fold', C.c_void_p),
     ]
@@ -41,7 +42,7 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 6  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 7  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     'lvae_last_error': (C.c_char_p, []),
     'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv2d_bf16': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_folds_bn_finalize': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_prepare_entry_bytes': (_Z, []),

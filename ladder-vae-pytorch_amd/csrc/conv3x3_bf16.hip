@@ -1,0 +1,391 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and dgrad) on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+// gfx950 issues a bf16 MFMA 16x faster than the fp32 one (1024 vs 64 FLOP/clk/SIMD), and the fp32 MFMA is what bounds the
+// large 3x3 layers of the fp32 model. Two precisions share this kernel:
+//
+//   SPLIT = 1  bf16 operands: activations and weights are rounded to bf16 at the MFMA input, products are exact, sums fp32
+//              (the arithmetic of the reference under torch.autocast(bfloat16); BASELINE configs[1], [3], [4]).
+//   SPLIT = 3  fp32-equivalent: every operand is split exactly into three bf16 pieces a = a1 + a2 + a3 (8 + 8 + 8 significant
+//              bits; each remainder is exact in fp32) and the product is formed from the six piece pairs of order <= 2^-16:
+//              a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 — what is dropped is below 2^-24 of the product, i.e. below the
+//              rounding an fp32 multiply-add makes anyway. Six bf16 MFMAs cost 6/16 of one fp32 MFMA of the same shape:
+//              2.7x the fp32-MFMA rate, and (unlike the fp32 MFMA) they leave the vector ALU free for the splits.
+//
+// Structure (as conv3x3_halo.hip): a workgroup stages the halo patch of its 128-pixel output tile once — input transform
+// (BatchNorm-apply + activation) applied once per element, then split — as SPLIT bf16 planes in LDS; per tap the 64 x 64
+// weight tile is split into planes too (double buffered, register prefetch one tap ahead); A and B fragments are 16-byte
+// ds_read_b128 of 8 consecutive reduction channels (rows padded to 144 bytes: conflict free); epilogue through LDS with
+// bias, Dropout2d scale, activation and the BatchNorm statistics / BatchNorm-backward sums of conv3x3_halo.hip.
+#include "lvae_common.h"
+
+namespace lvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct BfArgs {
+  lvae_conv_desc d;
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, flip, Cin;
+  uint32_t m_thw, m_tw, m_per_img, m_halo_w;
+};
+
+constexpr int kBfNotEligible = -1000;
+constexpr int BF_BM = 128;   // output pixels per workgroup
+constexpr int BF_LDK = 72;   // bf16 elements per LDS row (64 channels + 8 pad = 144 bytes)
+
+template <int SPLIT>
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      const __bf16 b = (__bf16)r;
+      out[p][j] = b;
+      if (p + 1 < SPLIT) r -= (float)b;  // exact: the remainder of a round-to-nearest to 8 bits has at most 16 significant bits
+    }
+  }
+}
+
+template <int SPLIT, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
+  constexpr int BM = BF_BM, LDK = BF_LDK, MI = 2;
+  constexpr int BPL = 64 * LDK;  // bf16 elements of one weight plane of one tap
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                    // [SPLIT][halo_px][LDK]
+  const int a_plane = a.halo_px * LDK;
+  __bf16* Bs = As + (size_t)SPLIT * a_plane;                            // [2][SPLIT][64][LDK]
+
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.ntn;
+  const int tm = bid / a.ntn;
+  const int th_idx = tm % a.tiles_h, ig = tm / a.tiles_h;
+  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
+  const int Cin = a.Cin;
+
+  // ---- weights of one tap -> registers (16 floats per thread), later split -> LDS planes [n][k]
+  f32x4 breg[4];
+  auto load_b = [&](int tap) {
+    const float* wt = d.w + (int64_t)tap * d.w_stap;
+    if (B_KCONTIG) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = t + 256 * u, n = idx >> 4, k = (idx & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (co0 + n < d.Cout && k < Cin) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)(co0 + n) * d.w_sn + k);
+        breg[u] = v;
+      }
+    } else {
+      // n-contiguous weights: lane -> output channel (coalesced), thread gathers 4 consecutive reduction channels
+      const int n = t & 63, kq = t >> 6;
+      const bool n_ok = co0 + n < d.Cout;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = (kq + 4 * u) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (n_ok && k + j < Cin) ? wt[(int64_t)(k + j) * d.w_sk + co0 + n] : 0.f;
+        breg[u] = v;
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+    __bf16* Bb = Bs + (size_t)buf * SPLIT * BPL;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int n, k;
+      if (B_KCONTIG) {
+        const int idx = t + 256 * u;
+        n = idx >> 4;
+        k = (idx & 15) * 4;
+      } else {
+        n = t & 63;
+        k = ((t >> 6) + 4 * u) * 4;
+      }
+      bf16x4 pl[SPLIT];
+      split4<SPLIT>(breg[u], pl);
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<bf16x4*>(Bb + p * BPL + n * LDK + k) = pl[p];
+    }
+  };
+
+  load_b(0);
+
+  // ---- halo patch: every (pixel, 4 channels) once; transform fused, split into planes, zeros outside the image / batch
+  {
+    const int per_img = a.halo_h * a.halo_w;
+    const int total = a.halo_px * 16;
+    const int c4 = (t & 15) * 4;
+    const bool c_ok = c4 < Cin;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (d.in_scale && c_ok) {
+      sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
+      sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
+    }
+    const float* xc = d.x + c4;
+    const int px0 = t >> 4;
+    for (int base = 0; base < total; base += 256 * 8) {
+      f32x4 v[8];
+      unsigned okm = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + t + 256 * u;
+        const int px = (base >> 4) + px0 + u * 16;
+        const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+        const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+        const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+        const bool ok = (idx < total) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & c_ok;
+        const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin) : 0u;
+        v[u] = *reinterpret_cast<const f32x4*>(xc + off);
+        okm |= ok ? (1u << u) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + t + 256 * u;
+        if (idx < total) {
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if ((okm >> u) & 1u) {
+            w = v[u];
+            if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
+          }
+          const int px = (base >> 4) + px0 + u * 16;
+          bf16x4 pl[SPLIT];
+          split4<SPLIT>(w, pl);
+#pragma unroll
+          for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<bf16x4*>(As + p * a_plane + px * LDK + c4) = pl[p];
+        }
+      }
+    }
+  }
+  store_b(0);
+
+  // ---- per-lane halo row of its A-fragment pixels (element offset inside a plane)
+  const int tile_px = a.NI * a.TH * a.TW;
+  int hbase[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int p = wm * 64 + mi * 32 + li;
+    if (p >= tile_px) p = 0;
+    const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
+    const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
+    hbase[mi] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDK + 8 * lh;
+  }
+
+  f32x16 acc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+  __syncthreads();
+
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int buf = tap & 1;
+    if (tap + 1 < 9) load_b(tap + 1);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
+    const int tapoff = (dh * a.halo_w + dw) * LDK;
+    const __bf16* Bb = Bs + (size_t)buf * SPLIT * BPL + (wn * 32 + li) * LDK + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[MI][SPLIT], bf[SPLIT];
+#pragma unroll
+      for (int p = 0; p < SPLIT; ++p) {
+        bf[p] = *reinterpret_cast<const bf16x8*>(Bb + p * BPL + ks * 16);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi][p] = *reinterpret_cast<const bf16x8*>(As + p * a_plane + hbase[mi] + tapoff + ks * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if (SPLIT == 1) {
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], acc[mi], 0, 0, 0);
+        } else {
+          // smallest terms first
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SPLIT - 1], bf[0], acc[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[SPLIT - 1], acc[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[1], acc[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[0], acc[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[1], acc[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], acc[mi], 0, 0, 0);
+        }
+      }
+    }
+    if (tap + 1 < 9) store_b(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (as conv3x3_halo.hip): accumulators -> LDS tile [BM][68] floats -> 16-byte row stores
+  constexpr int LDO = 68;
+  float* Os = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Os[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
+  __syncthreads();
+  const int c4 = (t & 15) * 4, col = co0 + c4;
+  f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
+  if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
+  f32x4 bsh = piv, bmu = piv, brs = piv;
+  if (d.stats_out && d.stats_mode == LVAE_STATS_BN_BWD && col < d.Cout) {
+    bsh = *reinterpret_cast<const f32x4*>(d.stats_pivot + d.Cout + col);
+    bmu = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col);
+    brs = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col);
+  }
+  if (col < d.Cout) {
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
+    const int p0 = t >> 4;
+    float* yp = d.y + ((size_t)(n0 * d.H + oh0) * d.W + p0) * d.Cout + col;
+    const float* op = Os + p0 * LDO + c4;
+    const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
+#pragma unroll
+    for (int q = 0; q < BM / 16; ++q) {
+      const int p = p0 + 16 * q;
+      if (p < nvalid) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias;
+        if (d.out_scale) {
+          const int n = n0 + fastdiv(p, a.m_thw);
+          v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
+        }
+        v = act_fwd4(v, d.out_act);
+        *reinterpret_cast<f32x4*>(yp + (size_t)q * 16 * d.Cout) = v;
+        if (d.stats_mode == LVAE_STATS_BN_BWD) {
+          if (d.stats_out) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+              st1[j] += gj;
+              st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
+            }
+          }
+        } else {
+          const f32x4 dl = v - piv;
+          st1 += dl;
+          st2 += dl * dl;
+        }
+      }
+    }
+  }
+  if (d.stats_out) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);
+    *reinterpret_cast<f32x4*>(red + (t >> 4) * 64 + c4) = st1;
+    *reinterpret_cast<f32x4*>(red + 1024 + (t >> 4) * 64 + c4) = st2;
+    __syncthreads();
+    if (t < 128) {
+      const int c = t & 63, which = t >> 6;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[which * 1024 + r * 64 + c];
+      if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
+    }
+  }
+}
+
+static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static size_t bf_lds_bytes(int split, int halo_px) {
+  const size_t in = ((size_t)split * halo_px * BF_LDK + (size_t)2 * split * 64 * BF_LDK) * 2;
+  const size_t out = (size_t)BF_BM * 68 * 4;
+  return in > out ? in : out;
+}
+
+// tile geometry for a W-wide image (as conv3x3_halo.hip): rows per tile and images per tile so that NI*TH*W <= 128
+static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
+  const int N = d->N, H = d->H, W = d->W;
+  if (W > BF_BM) return false;
+  int TH = 1;
+  for (int c = 1; c <= H; ++c)
+    if (H % c == 0 && c * W <= BF_BM) TH = c;
+  int NI = BF_BM / (TH * W);
+  if (NI < 1) NI = 1;
+  if (TH < H) NI = 1;
+  if (NI > N) NI = N;
+  a.TH = TH;
+  a.TW = W;
+  a.NI = NI;
+  a.tiles_h = H / TH;
+  a.halo_h = TH + 2;
+  a.halo_w = W + 2;
+  a.halo_px = NI * a.halo_h * a.halo_w;
+  a.m_thw = fastdiv_magic(TH * W);
+  a.m_tw = fastdiv_magic(W);
+  a.m_per_img = fastdiv_magic(a.halo_h * a.halo_w);
+  a.m_halo_w = fastdiv_magic(a.halo_w);
+  return bf_lds_bytes(split, a.halo_px) <= 160 * 1024;
+}
+
+static bool bf_select(const lvae_conv_desc* d, int split, BfArgs& a, bool& ncontig) {
+  const int Cin = d->C1;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;
+  if (d->in_fold != nullptr) return false;
+  if (Cin > 64 || Cin % 4 != 0 || d->Cout % 4 != 0 || d->w_stap % 4 != 0) return false;
+  if ((int64_t)d->N * d->H * d->W * Cin >= ((int64_t)1 << 31)) return false;
+  if (!al16b(d->x) || !al16b(d->w) || !al16b(d->y) || !al16b(d->bias) || !al16b(d->out_scale) || !al16b(d->in_scale) ||
+      !al16b(d->in_shift) || !al16b(d->stats_pivot) || !al16b(d->stats_x))
+    return false;
+  const bool kc = d->w_sk == 1 && d->w_sn % 4 == 0, nc = d->w_sn == 1;
+  if (!kc && !nc) return false;
+  a.d = *d;
+  a.Cin = Cin;
+  a.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
+  if (!bf_plan(d, split, a)) return false;
+  ncontig = !kc;
+  return true;
+}
+
+bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split) {
+  BfArgs a;
+  bool nc;
+  return bf_select(d, split, a, nc);
+}
+
+int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split) {
+  BfArgs a;
+  bool nc;
+  if (!bf_select(d, split, a, nc)) return 0;
+  return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
+}
+
+template <int SPLIT, bool KC>
+static int launch_bf(BfArgs a, hipStream_t s) {
+  auto kern = conv3x3_bf16_kernel<SPLIT, KC>;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv3x3_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  const int img_groups = (a.d.N + a.NI - 1) / a.NI;
+  a.ntn = (a.d.Cout + 63) / 64;
+  a.d.in_fold = nullptr;
+  hipLaunchKernelGGL(kern, dim3(img_groups * a.tiles_h * a.ntn), dim3(256), bf_lds_bytes(SPLIT, a.halo_px), s, a);
+  LVAE_LAUNCH_CHECK("conv3x3_bf16");
+  return 0;
+}
+
+// split = 1: bf16 operands; split = 3: fp32-equivalent six-product form. Returns kBfNotEligible when the descriptor does not fit.
+int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
+  BfArgs a;
+  bool ncontig = false;
+  if (!bf_select(d, split, a, ncontig)) return kBfNotEligible;
+  if (split == 1) return ncontig ? launch_bf<1, false>(a, s) : launch_bf<1, true>(a, s);
+  return ncontig ? launch_bf<3, false>(a, s) : launch_bf<3, true>(a, s);
+}
+
+}  // namespace lvae

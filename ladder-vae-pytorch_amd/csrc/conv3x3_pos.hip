@@ -99,9 +99,21 @@ __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
     const int rows = f.rows;
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
-      for (int r = g; r < rows; r += G) {
-        s1 += f.parts[((size_t)r * 2) * C + c];
-        s2 += f.parts[((size_t)r * 2 + 1) * C + c];
+      for (int r = g; r < rows; r += 8 * G) {  // 16 independent loads per round trip (a rolled loop pays one L2 latency per row)
+        float pa[8], pb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = r + u * G;
+          const size_t o = ((size_t)(rr < rows ? rr : g) * 2) * C + c;
+          pa[u] = f.parts[o];
+          pb[u] = f.parts[o + C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = r + u * G < rows;
+          s1 += ok ? pa[u] : 0.f;
+          s2 += ok ? pb[u] : 0.f;
+        }
       }
     s_fin[(g * 2) * 64 + c] = s1;
     s_fin[(g * 2 + 1) * 64 + c] = s2;

@@ -353,6 +353,9 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
   return 0;
 }
 
+int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s);
+int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split);
+bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split);
 int conv3x3_pos_try(const lvae_conv_desc* d, hipStream_t s);
 int conv3x3_pos_stats_rows(const lvae_conv_desc* d);
 bool conv3x3_pos_eligible(const lvae_conv_desc* d);
@@ -368,12 +371,25 @@ int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_o
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Which bf16-matrix-pipe form (conv3x3_bf16.hip) a 3x3 descriptor takes: 1 = bf16 operands (precision LVAE_PREC_BF16), 3 = the
+// fp32-equivalent six-product split for the large fp32 layers (LVAE_F32_SPLIT=0 keeps them on the fp32 MFMA / Winograd
+// kernels), 0 = neither.
+static int bf16_form(const lvae_conv_desc* d) {
+  if (d->precision == LVAE_PREC_BF16) return conv3x3_bf16_eligible(d, 1) ? 1 : 0;
+  const char* sw = getenv("LVAE_F32_SPLIT");  // A/B switch, read per call (the parity tests run both forms in one process)
+  const bool split_on = sw == nullptr || atoi(sw) != 0;
+  static const int64_t min_m = getenv("LVAE_F32_SPLIT_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_MIN_M")) : 256 * 64;  // tuning switch
+  if (!split_on || (int64_t)d->N * d->H * d->W < min_m) return 0;
+  return conv3x3_bf16_eligible(d, 3) ? 3 : 0;
+}
+
 }  // namespace lvae
 
 using namespace lvae;
 
 extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
   if (d == nullptr) return 0;
+  if (!conv3x3_pos_eligible(d) && bf16_form(d) != 0) return 0;  // the bf16-pipe kernels split their weights themselves
   return conv3x3_wino_eligible(d) ? conv3x3_wino_workspace(d) : 0;
 }
 
@@ -381,6 +397,8 @@ extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
   if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
   const int p = conv3x3_pos_stats_rows(d);
   if (p > 0) return p;
+  const int form = bf16_form(d);
+  if (form != 0) return conv3x3_bf16_stats_rows(d, form);
   const int w = conv3x3_wino_stats_rows(d);
   if (w > 0) return w;
   if (d->workspace != nullptr && conv3x3_wino_eligible(d) && (size_t)d->workspace_bytes >= conv3x3_wino_workspace(d)) return 0;
@@ -408,6 +426,11 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   if (!halo_off) {
     int hr = conv3x3_pos_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;
+    const int form = bf16_form(d);
+    if (form != 0) {
+      hr = conv3x3_bf16_try(d, form, (hipStream_t)stream);
+      if (hr != -1000) return hr;
+    }
     hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);
     if (hr != -1000) return hr;
     hr = conv3x3_halo_try(d, (hipStream_t)stream);
@@ -437,6 +460,13 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   if (d->w_sn == 1 && w16 && d->Cout % 4 == 0 && d->w_sk % 4 == 0) return dispatch_tile<true, B_NCONTIG>(a, s);
   if (d->w_sk == 1 && w16 && a.Cin % 4 == 0 && d->w_sn % 4 == 0) return dispatch_tile<true, B_KCONTIG>(a, s);
   return dispatch_tile<true, B_SCALAR>(a, s);
+}
+
+extern "C" int lvae_conv2d_bf16(const lvae_conv_desc* d, void* stream) {
+  LVAE_REQUIRE(d != nullptr, LVAE_EINVAL, "lvae_conv2d_bf16: null descriptor");
+  lvae_conv_desc dd = *d;
+  dd.precision = LVAE_PREC_BF16;
+  return lvae_conv2d_f32(&dd, stream);
 }
 
 // GateLayer2d forward fused with its 1x1 convolution and the residual add (lib/nn.py:118-126, 99):

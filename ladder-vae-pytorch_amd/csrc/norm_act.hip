@@ -333,9 +333,21 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
     const int nsl = 256 / cols;
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
     if (rg < nsl)
-      for (int r = rg; r < rows; r += nsl) {
-        a += *reinterpret_cast<const f32x4*>(parts + (size_t)r * 2 * C + c);
-        b += *reinterpret_cast<const f32x4*>(parts + (size_t)r * 2 * C + C + c);
+      for (int r = rg; r < rows; r += 4 * nsl) {  // 8 independent 16-byte loads per round trip, summed in row order
+        f32x4 pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int rr = r + u * nsl;
+          const size_t o = (size_t)(rr < rows ? rr : rg) * 2 * C + c;
+          pa[u] = *reinterpret_cast<const f32x4*>(parts + o);
+          pb[u] = *reinterpret_cast<const f32x4*>(parts + o + C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (r + u * nsl < rows) {
+            a += pa[u];
+            b += pb[u];
+          }
       }
     *reinterpret_cast<f32x4*>(&red[0][t * 4]) = a;
     *reinterpret_cast<f32x4*>(&red[1][t * 4]) = b;

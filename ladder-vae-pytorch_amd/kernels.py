@@ -10,9 +10,19 @@ import weakref
 import torch
 
 from . import _C
-from ._C import ACT, BnFold, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, call, ptr, stream_ptr
+from ._C import ACT, BnFold, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, PREC_BF16, PREC_F32, call, ptr, stream_ptr
 
 _ws_cache = {}
+
+# Arithmetic of the matrix-core kernels for every convolution descriptor built from here on: PREC_F32 (results as an fp32
+# multiply-add chain) or PREC_BF16 (operands rounded to bf16 at the MFMA input, fp32 accumulate). LadderVAE sets it from its
+# `compute_dtype` at the start of every pass; backward launches of that pass follow before the next forward.
+precision = PREC_F32
+
+
+def set_precision(dtype):
+    global precision
+    precision = {'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32, 'bf16': PREC_BF16, 'bfloat16': PREC_BF16}[str(dtype).replace('torch.', '')]
 
 
 def workspace(nbytes, device):
@@ -70,6 +80,7 @@ def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, b
     d.y = ptr(y)
     d.N, d.H, d.W, d.OH, d.OW, d.Cout = N, H, W, OH, OW, Cout
     d.KH, d.KW, d.stride, d.pad, d.gather = g.KH, g.KW, g.stride, g.pad, gather
+    d.precision = precision
     return d
 
 

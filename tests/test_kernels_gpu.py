@@ -108,10 +108,13 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('form', ['winograd', 'split'])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_conv3x3_winograd(K, case):
-    """Large 3x3 stride-1 layers take the Winograd F(2x2,3x3) kernel (forward and dgrad) when given scratch; it must agree
-    with the direct fp32 sum to a few ulp, including the fused BN/activation prologue and dropout/activation epilogue."""
+def test_conv3x3_winograd(K, case, form, monkeypatch):
+    """Large 3x3 stride-1 layers run either as Winograd F(2x2,3x3) on the fp32 MFMA (LVAE_F32_SPLIT=0) or as six exact bf16-piece
+    products per fp32 product on the bf16 MFMA (the default where the shape fits); both must agree with the direct sum to a few
+    ulp of fp32, including the fused BN/activation prologue and dropout/activation epilogue."""
+    monkeypatch.setenv('LVAE_F32_SPLIT', '0' if form == 'winograd' else '1')
     N, Co, H, W = case
     C = 64
     g = torch.Generator().manual_seed(sum(case))
@@ -125,7 +128,8 @@ def test_conv3x3_winograd(K, case):
     wp = packed_weight(w)
     geom = K.ConvGeom(wp, 1, 1)
     d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
-    assert K._C.load().lvae_conv2d_workspace(ctypes.byref(d)) > 0, "case is meant to exercise the Winograd path"
+    if form == 'winograd':
+        assert K._C.load().lvae_conv2d_workspace(ctypes.byref(d)) > 0, "case is meant to exercise the Winograd path"
     yd = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
                   out_scale=drop.cuda(), out_act='elu')
     assert rel(nchw(yd), y) < 4e-6
@@ -635,3 +639,40 @@ def test_bn_finalize_folded_into_the_consuming_convolution(K, case):
     torch.testing.assert_close(sc.cpu(), gamma * rstd.cpu(), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(bn.running_mean.cpu(), rmr, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(bn.running_var.cpu(), rvr, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (49, 64, 64, 32, 32), (300, 32, 64, 8, 8), (70, 64, 100, 16, 16)])
+def test_conv3x3_bf16_operands(K, case):
+    """precision = bf16 (lvae_conv2d_bf16): operands rounded to bf16, exact products, fp32 accumulation — against torch's fp32
+    convolution on inputs that were rounded to bf16 beforehand (then the only difference is summation order), and within bf16
+    rounding of the unrounded fp32 result. Forward with the fused BN+ELU prologue, dgrad with the Dropout2d scale."""
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    sc, sh = 1 + 0.1 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    bf = lambda t: t.bfloat16().float()
+    xin = F.elu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref_rounded = F.conv2d(bf(xin).double(), bf(w).double(), b.double(), padding=1).float()
+    ref_full = F.conv2d(xin, w, b, padding=1)
+    K.set_precision('bf16')
+    try:
+        y, parts = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
+                            stats_pivot=torch.zeros(Co, device='cuda'))
+        dy = torch.randn(N, Co, H, W, generator=g)
+        dx = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W)) if Co <= 64 else None
+    finally:
+        K.set_precision('f32')
+    # the fused transform is evaluated in fp32 on the GPU (fast exp): a value that lands within 1e-6 of a bf16 rounding boundary may
+    # round the other way than on the CPU, so the "same rounded inputs" comparison holds to ~1e-4 rather than to fp32 ulps
+    assert rel(nchw(y), ref_rounded) < 2e-4
+    assert rel(nchw(y), ref_full) < 6e-3
+    assert parts is not None
+    s = parts.rows_view().sum(0).cpu()
+    torch.testing.assert_close(s[0], nchw(y).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    if dx is not None:
+        dref = F.conv_transpose2d(bf(dy).double(), bf(w).double(), padding=1).float()
+        assert rel(nchw(dx), dref) < 1e-5
