@@ -16,6 +16,8 @@
 // weight tile is split into planes too (double buffered, register prefetch one tap ahead); A and B fragments are 16-byte
 // ds_read_b128 of 8 consecutive reduction channels (rows padded to 144 bytes: conflict free); epilogue through LDS with
 // bias, Dropout2d scale, activation and the BatchNorm statistics / BatchNorm-backward sums of conv3x3_halo.hip.
+#include <string.h>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -25,6 +27,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct BfArgs {
   lvae_conv_desc d;
+  const __bf16* Wp;  // pre-split weights [tap][Cout tile][plane][64 n][64 k] (bf_weight_kernel / lvae_conv2d_prepare_weights)
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, flip, Cin;
   uint32_t m_thw, m_tw, m_per_img, m_halo_w;
 };
@@ -47,7 +50,7 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
   }
 }
 
-template <int SPLIT, bool B_KCONTIG>
+template <int SPLIT>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
   constexpr int BM = BF_BM, LDK = BF_LDK, MI = 2;
   constexpr int BPL = 64 * LDK;  // bf16 elements of one weight plane of one tap
@@ -71,53 +74,27 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
   const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
   const int Cin = a.Cin;
 
-  // ---- weights of one tap -> registers (16 floats per thread), later split -> LDS planes [n][k]
-  f32x4 breg[4];
-  auto load_b = [&](int tap) {
-    const float* wt = d.w + (int64_t)tap * d.w_stap;
-    if (B_KCONTIG) {
+  // ---- weights: pre-split bf16 planes of one tap (SPLIT x 8 KB, L2 resident) -> register ring (two taps ahead: one tap is only
+  // 0.1-0.7 us of MFMAs, shorter than an L2 round trip) -> LDS planes [n][k] padded to 144-byte rows
+  constexpr int BV = SPLIT * 2;  // 16-byte vectors of a tap per thread
+  bf16x8 breg[3][BV];
+  const __bf16* wp_tile = a.Wp + (size_t)tile_n * SPLIT * 4096;
+  auto load_b = [&](int tap, bf16x8 (&r)[BV]) {
+    const __bf16* src = wp_tile + (size_t)tap * a.ntn * SPLIT * 4096;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = t + 256 * u, n = idx >> 4, k = (idx & 15) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (co0 + n < d.Cout && k < Cin) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)(co0 + n) * d.w_sn + k);
-        breg[u] = v;
-      }
-    } else {
-      // n-contiguous weights: lane -> output channel (coalesced), thread gathers 4 consecutive reduction channels
-      const int n = t & 63, kq = t >> 6;
-      const bool n_ok = co0 + n < d.Cout;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = (kq + 4 * u) * 4;
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (n_ok && k + j < Cin) ? wt[(int64_t)(k + j) * d.w_sk + co0 + n] : 0.f;
-        breg[u] = v;
-      }
-    }
+    for (int u = 0; u < BV; ++u) r[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)(t + 256 * u) * 8);
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, const bf16x8 (&r)[BV]) {
     __bf16* Bb = Bs + (size_t)buf * SPLIT * BPL;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int n, k;
-      if (B_KCONTIG) {
-        const int idx = t + 256 * u;
-        n = idx >> 4;
-        k = (idx & 15) * 4;
-      } else {
-        n = t & 63;
-        k = ((t >> 6) + 4 * u) * 4;
-      }
-      bf16x4 pl[SPLIT];
-      split4<SPLIT>(breg[u], pl);
-#pragma unroll
-      for (int p = 0; p < SPLIT; ++p) *reinterpret_cast<bf16x4*>(Bb + p * BPL + n * LDK + k) = pl[p];
+    for (int u = 0; u < BV; ++u) {
+      const int v = t + 256 * u, p = v >> 9, idx = v & 511, n = idx >> 3, k = (idx & 7) * 8;
+      *reinterpret_cast<bf16x8*>(Bb + p * BPL + n * LDK + k) = r[u];
     }
   };
 
-  load_b(0);
+  load_b(0, breg[0]);
+  load_b(1, breg[1]);
 
   // ---- halo patch: every (pixel, 4 channels) once; transform fused, split into planes, zeros outside the image / batch
   {
@@ -165,7 +142,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
       }
     }
   }
-  store_b(0);
+  store_b(0, breg[0]);
 
   // ---- per-lane halo row of its A-fragment pixels (element offset inside a plane)
   const int tile_px = a.NI * a.TH * a.TW;
@@ -187,10 +164,10 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
 
   __syncthreads();
 
-#pragma unroll 1
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int buf = tap & 1;
-    if (tap + 1 < 9) load_b(tap + 1);
+    if (tap + 2 < 9) load_b(tap + 2, breg[(tap + 2) % 3]);  // ring slot (tap + 2) % 3 was stored to LDS one tap ago
     const int kh = tap / 3, kw = tap - kh * 3;
     const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
     const int tapoff = (dh * a.halo_w + dw) * LDK;
@@ -220,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
         }
       }
     }
-    if (tap + 1 < 9) store_b(buf ^ 1);
+    if (tap + 1 < 9) store_b(buf ^ 1, breg[(tap + 1) % 3]);
     __syncthreads();
   }
 
@@ -296,6 +273,68 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
 
 static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- weight pre-split: Wp[tap][Cout tile][plane][n][k] = piece `plane` of w[tap][k][n] (any strides), zero beyond K / N
+struct BfPrepEntry {   // same 64 bytes as the Winograd entry of conv3x3_wino.hip (lvae_conv2d_prepare_entry); kind = planes (1 | 3)
+  const float* w;
+  __bf16* U;
+  int64_t stap, sk, sn;
+  int32_t K, N, Npad, flip;
+  int32_t Kpad, kind;
+};
+static_assert(sizeof(BfPrepEntry) == 64, "entry layout is part of the C ABI (lvae_conv2d_prepare_entry)");
+
+__device__ __forceinline__ void bf_prep_element(const BfPrepEntry& e, int idx) {
+  // idx -> (n, k): consecutive threads take consecutive k (the destination rows are k-contiguous)
+  const int k = idx & 63, n = idx >> 6;
+  if (n >= e.Npad) return;
+  const int ntn = e.Npad >> 6, tn = n >> 6, nn = n & 63;
+  for (int tap = 0; tap < 9; ++tap) {
+    float r = (n < e.N && k < e.K) ? e.w[tap * e.stap + (int64_t)k * e.sk + (int64_t)n * e.sn] : 0.f;
+    __bf16* dst = e.U + ((size_t)(tap * ntn + tn) * e.kind) * 4096 + nn * 64 + k;
+    for (int p = 0; p < e.kind; ++p) {
+      const __bf16 b = (__bf16)r;
+      dst[(size_t)p * 4096] = b;
+      r -= (float)b;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bf_weight_kernel(BfPrepEntry e) { bf_prep_element(e, blockIdx.x * 256 + threadIdx.x); }
+
+// the entries of a batched pre-transform table (lvae_conv2d_prepare_weights) whose kind != 0; the Winograd kernel takes the others
+__global__ __launch_bounds__(256) void bf_weight_batched_kernel(const BfPrepEntry* __restrict__ entries) {
+  const BfPrepEntry e = entries[blockIdx.y];
+  if (e.kind == 0) return;
+  bf_prep_element(e, blockIdx.x * 256 + threadIdx.x);
+}
+
+int conv3x3_bf16_prepare_batched(const void* entries, int n, int npad, hipStream_t s) {
+  hipLaunchKernelGGL(bf_weight_batched_kernel, dim3((npad * 64 + 255) / 256, n), dim3(256), 0, s, static_cast<const BfPrepEntry*>(entries));
+  LVAE_LAUNCH_CHECK("bf_weight_batched");
+  return 0;
+}
+
+size_t conv3x3_bf16_workspace(const lvae_conv_desc* d, int split) {
+  const int ntn = (d->Cout + 63) / 64;
+  return (size_t)9 * ntn * split * 4096 * sizeof(__bf16);
+}
+
+void conv3x3_bf16_prep_entry(const lvae_conv_desc* d, int split, void* entry) {
+  BfPrepEntry e;
+  e.w = d->w;
+  e.U = static_cast<__bf16*>(d->workspace);
+  e.stap = d->w_stap;
+  e.sk = d->w_sk;
+  e.sn = d->w_sn;
+  e.K = d->C1;
+  e.N = d->Cout;
+  e.Npad = (d->Cout + 63) / 64 * 64;
+  e.flip = 0;
+  e.Kpad = 64;
+  e.kind = split;
+  memcpy(entry, &e, sizeof(e));
+}
+
 static size_t bf_lds_bytes(int split, int halo_px) {
   const size_t in = ((size_t)split * halo_px * BF_LDK + (size_t)2 * split * 64 * BF_LDK) * 2;
   const size_t out = (size_t)BF_BM * 68 * 4;
@@ -327,41 +366,46 @@ static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
   return bf_lds_bytes(split, a.halo_px) <= 160 * 1024;
 }
 
-static bool bf_select(const lvae_conv_desc* d, int split, BfArgs& a, bool& ncontig) {
+static bool bf_select(const lvae_conv_desc* d, int split, BfArgs& a) {
   const int Cin = d->C1;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;
   if (d->in_fold != nullptr) return false;
-  if (Cin > 64 || Cin % 4 != 0 || d->Cout % 4 != 0 || d->w_stap % 4 != 0) return false;
+  if (Cin > 64 || Cin % 4 != 0 || d->Cout % 4 != 0) return false;
   if ((int64_t)d->N * d->H * d->W * Cin >= ((int64_t)1 << 31)) return false;
-  if (!al16b(d->x) || !al16b(d->w) || !al16b(d->y) || !al16b(d->bias) || !al16b(d->out_scale) || !al16b(d->in_scale) ||
-      !al16b(d->in_shift) || !al16b(d->stats_pivot) || !al16b(d->stats_x))
+  if (!al16b(d->x) || !al16b(d->y) || !al16b(d->bias) || !al16b(d->out_scale) || !al16b(d->in_scale) || !al16b(d->in_shift) ||
+      !al16b(d->stats_pivot) || !al16b(d->stats_x))
     return false;
-  const bool kc = d->w_sk == 1 && d->w_sn % 4 == 0, nc = d->w_sn == 1;
-  if (!kc && !nc) return false;
   a.d = *d;
   a.Cin = Cin;
   a.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
-  if (!bf_plan(d, split, a)) return false;
-  ncontig = !kc;
-  return true;
+  return bf_plan(d, split, a);
 }
 
 bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split) {
   BfArgs a;
-  bool nc;
-  return bf_select(d, split, a, nc);
+  return bf_select(d, split, a);
+}
+
+// Which bf16-matrix-pipe form a 3x3 descriptor takes: 1 = bf16 operands (precision LVAE_PREC_BF16), 3 = the fp32-equivalent
+// six-product split for the large fp32 layers (LVAE_F32_SPLIT=0 keeps them on the fp32 MFMA / Winograd kernels), 0 = neither.
+int conv3x3_bf16_form(const lvae_conv_desc* d) {
+  if (d->precision == LVAE_PREC_BF16) return conv3x3_bf16_eligible(d, 1) ? 1 : 0;
+  const char* sw = getenv("LVAE_F32_SPLIT");  // A/B switch, read per call (the parity tests run both forms in one process)
+  const bool split_on = sw == nullptr || atoi(sw) != 0;
+  static const int64_t min_m = getenv("LVAE_F32_SPLIT_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_MIN_M")) : 256 * 64;  // tuning switch
+  if (!split_on || (int64_t)d->N * d->H * d->W < min_m) return 0;
+  return conv3x3_bf16_eligible(d, 3) ? 3 : 0;
 }
 
 int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split) {
   BfArgs a;
-  bool nc;
-  if (!bf_select(d, split, a, nc)) return 0;
+  if (d->workspace == nullptr || (size_t)d->workspace_bytes < conv3x3_bf16_workspace(d, split) || !bf_select(d, split, a)) return 0;
   return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
 }
 
-template <int SPLIT, bool KC>
+template <int SPLIT>
 static int launch_bf(BfArgs a, hipStream_t s) {
-  auto kern = conv3x3_bf16_kernel<SPLIT, KC>;
+  auto kern = conv3x3_bf16_kernel<SPLIT>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -379,13 +423,20 @@ static int launch_bf(BfArgs a, hipStream_t s) {
   return 0;
 }
 
-// split = 1: bf16 operands; split = 3: fp32-equivalent six-product form. Returns kBfNotEligible when the descriptor does not fit.
+// split = 1: bf16 operands; split = 3: fp32-equivalent six-product form. `d->workspace` holds the pre-split weights
+// (conv3x3_bf16_workspace bytes; written here first unless d->workspace_ready). Returns kBfNotEligible when the descriptor or the
+// scratch does not fit.
 int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
   BfArgs a;
-  bool ncontig = false;
-  if (!bf_select(d, split, a, ncontig)) return kBfNotEligible;
-  if (split == 1) return ncontig ? launch_bf<1, false>(a, s) : launch_bf<1, true>(a, s);
-  return ncontig ? launch_bf<3, false>(a, s) : launch_bf<3, true>(a, s);
+  if (d->workspace == nullptr || (size_t)d->workspace_bytes < conv3x3_bf16_workspace(d, split) || !al16b(d->workspace)) return kBfNotEligible;
+  if (!bf_select(d, split, a)) return kBfNotEligible;
+  if (!d->workspace_ready) {
+    BfPrepEntry e;
+    conv3x3_bf16_prep_entry(d, split, &e);
+    hipLaunchKernelGGL(bf_weight_kernel, dim3((e.Npad * 64 + 255) / 256), dim3(256), 0, s, e);
+  }
+  a.Wp = static_cast<const __bf16*>(d->workspace);
+  return split == 1 ? launch_bf<1>(a, s) : launch_bf<3>(a, s);
 }
 
 }  // namespace lvae

@@ -82,6 +82,7 @@ static_assert(sizeof(WinoPrepEntry) == 64, "entry layout is part of the C ABI (l
 __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrepEntry* __restrict__ entries) {
   const WinoPrepEntry e = entries[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (e.pad_ != 0) return;  // a pre-split bf16 entry: conv3x3_bf16.hip's batched kernel handles it
   if (idx >= e.Npad * e.Kpad) return;
   const int c = idx & 3, n = (idx >> 2) % e.Npad, kq = (idx >> 2) / e.Npad;
   const int k = kq * 4 + c;
@@ -460,8 +461,25 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_prepare_entry_bytes(void) { return sizeof(WinoPrepEntry); }
 
+namespace lvae {
+int conv3x3_bf16_form(const lvae_conv_desc* d);
+size_t conv3x3_bf16_workspace(const lvae_conv_desc* d, int split);
+void conv3x3_bf16_prep_entry(const lvae_conv_desc* d, int split, void* entry);
+int conv3x3_bf16_prepare_batched(const void* entries, int n, int npad, hipStream_t s);
+bool conv3x3_pos_eligible(const lvae_conv_desc* d);
+}  // namespace lvae
+
 extern "C" int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry) {
   LVAE_REQUIRE(d && entry, LVAE_EINVAL, "lvae_conv2d_prepare_entry: null pointer");
+  if (!conv3x3_pos_eligible(d)) {
+    const int form = conv3x3_bf16_form(d);
+    if (form != 0) {
+      LVAE_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= conv3x3_bf16_workspace(d, form) && al16w2(d->workspace), LVAE_EINVAL,
+                   "lvae_conv2d_prepare_entry: no scratch for the pre-split weights");
+      conv3x3_bf16_prep_entry(d, form, entry);
+      return 0;
+    }
+  }
   LVAE_REQUIRE(conv3x3_wino_eligible(d) && d->workspace && (size_t)d->workspace_bytes >= conv3x3_wino_workspace(d) &&
                    al16w2(d->workspace),
                LVAE_EINVAL, "lvae_conv2d_prepare_entry: descriptor has no weight pre-transform (lvae_conv2d_workspace(d) == 0) or no scratch");
@@ -487,5 +505,5 @@ extern "C" int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32
   hipLaunchKernelGGL(wino_weight_batched_kernel, dim3((npad * 128 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WinoPrepEntry*>(entries));
   LVAE_LAUNCH_CHECK("wino_weight_batched");
-  return 0;
+  return conv3x3_bf16_prepare_batched(entries, n, npad, (hipStream_t)stream);  // entries of the bf16-pipe kernels (kind != 0)
 }

@@ -355,7 +355,8 @@ int conv_desc_check(const lvae_conv_desc* d, const char* who) {
 
 int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s);
 int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split);
-bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split);
+int conv3x3_bf16_form(const lvae_conv_desc* d);
+size_t conv3x3_bf16_workspace(const lvae_conv_desc* d, int split);
 int conv3x3_pos_try(const lvae_conv_desc* d, hipStream_t s);
 int conv3x3_pos_stats_rows(const lvae_conv_desc* d);
 bool conv3x3_pos_eligible(const lvae_conv_desc* d);
@@ -371,25 +372,15 @@ int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_o
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Which bf16-matrix-pipe form (conv3x3_bf16.hip) a 3x3 descriptor takes: 1 = bf16 operands (precision LVAE_PREC_BF16), 3 = the
-// fp32-equivalent six-product split for the large fp32 layers (LVAE_F32_SPLIT=0 keeps them on the fp32 MFMA / Winograd
-// kernels), 0 = neither.
-static int bf16_form(const lvae_conv_desc* d) {
-  if (d->precision == LVAE_PREC_BF16) return conv3x3_bf16_eligible(d, 1) ? 1 : 0;
-  const char* sw = getenv("LVAE_F32_SPLIT");  // A/B switch, read per call (the parity tests run both forms in one process)
-  const bool split_on = sw == nullptr || atoi(sw) != 0;
-  static const int64_t min_m = getenv("LVAE_F32_SPLIT_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_MIN_M")) : 256 * 64;  // tuning switch
-  if (!split_on || (int64_t)d->N * d->H * d->W < min_m) return 0;
-  return conv3x3_bf16_eligible(d, 3) ? 3 : 0;
-}
-
 }  // namespace lvae
 
 using namespace lvae;
 
 extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
   if (d == nullptr) return 0;
-  if (!conv3x3_pos_eligible(d) && bf16_form(d) != 0) return 0;  // the bf16-pipe kernels split their weights themselves
+  if (conv3x3_pos_eligible(d)) return 0;
+  const int form = conv3x3_bf16_form(d);
+  if (form != 0) return conv3x3_bf16_workspace(d, form);  // pre-split bf16 weight planes
   return conv3x3_wino_eligible(d) ? conv3x3_wino_workspace(d) : 0;
 }
 
@@ -397,7 +388,7 @@ extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
   if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
   const int p = conv3x3_pos_stats_rows(d);
   if (p > 0) return p;
-  const int form = bf16_form(d);
+  const int form = conv3x3_bf16_form(d);
   if (form != 0) return conv3x3_bf16_stats_rows(d, form);
   const int w = conv3x3_wino_stats_rows(d);
   if (w > 0) return w;
@@ -426,7 +417,7 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   if (!halo_off) {
     int hr = conv3x3_pos_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;
-    const int form = bf16_form(d);
+    const int form = conv3x3_bf16_form(d);
     if (form != 0) {
       hr = conv3x3_bf16_try(d, form, (hipStream_t)stream);
       if (hr != -1000) return hr;

@@ -120,7 +120,7 @@ class _PreparedWeights:
         return len(dead)
 
     def attach(self, d, weight, device, need):
-        key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, device.index)
+        key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, int(need), device.index)   # `need` tells the transform kinds apart
         ent = self.entries.get(key)
         if ent is not None and not self._alive(ent):   # the address was recycled for another tensor
             del self.entries[key]
