@@ -12,10 +12,13 @@
 //              2.7x the fp32-MFMA rate, and (unlike the fp32 MFMA) they leave the vector ALU free for the splits.
 //
 // Structure (as conv3x3_halo.hip): a workgroup stages the halo patch of its 128-pixel output tile once — input transform
-// (BatchNorm-apply + activation) applied once per element, then split — as SPLIT bf16 planes in LDS; per tap the 64 x 64
-// weight tile is split into planes too (double buffered, register prefetch one tap ahead); A and B fragments are 16-byte
-// ds_read_b128 of 8 consecutive reduction channels (rows padded to 144 bytes: conflict free); epilogue through LDS with
-// bias, Dropout2d scale, activation and the BatchNorm statistics / BatchNorm-backward sums of conv3x3_halo.hip.
+// (BatchNorm-apply + activation) applied once per element, then split — as SPLIT bf16 planes in LDS (A fragments: 16-byte
+// ds_read_b128 of 8 consecutive reduction channels, rows padded to 144 bytes: conflict free). The weights never touch LDS: they
+// are pre-split once per optimizer step into planes stored in MFMA FRAGMENT ORDER (bf_weight_kernel), so a wave's B fragment is
+// one coalesced 1 KB load from L2, prefetched two k-steps ahead in registers. With no weights in LDS there is no barrier in
+// the reduction loop and the patch alone (<= 80 KB) lets two workgroups share a CU: one's loads overlap the other's MFMAs.
+// Epilogue through LDS with bias, Dropout2d scale, activation and the BatchNorm statistics / BatchNorm-backward sums of
+// conv3x3_halo.hip.
 #include <string.h>
 
 #include "lvae_common.h"
@@ -27,13 +30,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct BfArgs {
   lvae_conv_desc d;
-  const __bf16* Wp;  // pre-split weights [tap][Cout tile][plane][64 n][64 k] (bf_weight_kernel / lvae_conv2d_prepare_weights)
+  const __bf16* Wp;  // pre-split weights in fragment order [tap][Cout tile][k-step 4][plane][n half 2][lane 64][8] (bf_weight_kernel)
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, flip, Cin;
   uint32_t m_thw, m_tw, m_per_img, m_halo_w;
+  int bm;     // output pixels per workgroup (64 | 128)
+  int debug;  // phase-skip builds only (-DLVAE_PHASE_DEBUG): 1 = no halo staging, 2 = no epilogue, 4 = no MFMAs, 8 = no weight staging
 };
 
 constexpr int kBfNotEligible = -1000;
-constexpr int BF_BM = 128;   // output pixels per workgroup
 constexpr int BF_LDK = 72;   // bf16 elements per LDS row (64 channels + 8 pad = 144 bytes)
 
 template <int SPLIT>
@@ -50,14 +54,13 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
   }
 }
 
-template <int SPLIT>
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
-  constexpr int BM = BF_BM, LDK = BF_LDK, MI = 2;
-  constexpr int BPL = 64 * LDK;  // bf16 elements of one weight plane of one tap
+// MI: 32-pixel MFMA row blocks per wave; the workgroup tile is BM = 64 * MI output pixels x 64 output channels, 4 waves 2(M) x 2(N)
+template <int SPLIT, int MI>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
+  constexpr int BM = 64 * MI, LDK = BF_LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                    // [SPLIT][halo_px][LDK]
   const int a_plane = a.halo_px * LDK;
-  __bf16* Bs = As + (size_t)SPLIT * a_plane;                            // [2][SPLIT][64][LDK]
 
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -74,30 +77,22 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
   const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
   const int Cin = a.Cin;
 
-  // ---- weights: pre-split bf16 planes of one tap (SPLIT x 8 KB, L2 resident) -> register ring (two taps ahead: one tap is only
-  // 0.1-0.7 us of MFMAs, shorter than an L2 round trip) -> LDS planes [n][k] padded to 144-byte rows
-  constexpr int BV = SPLIT * 2;  // 16-byte vectors of a tap per thread
-  bf16x8 breg[3][BV];
-  const __bf16* wp_tile = a.Wp + (size_t)tile_n * SPLIT * 4096;
-  auto load_b = [&](int tap, bf16x8 (&r)[BV]) {
-    const __bf16* src = wp_tile + (size_t)tap * a.ntn * SPLIT * 4096;
+  // ---- weights: this wave's B fragments of k-step s = tap * 4 + ks, one 16-byte load per plane (1 KB per wave, contiguous)
+  bf16x8 bq[3][SPLIT];
+  const __bf16* wp_lane = a.Wp + (size_t)tile_n * 4 * SPLIT * 1024 + (size_t)wn * 512 + (size_t)lane * 8;
+  auto load_b = [&](int step, bf16x8 (&r)[SPLIT]) {
+    const int tap = step >> 2, ks = step & 3;
+    const __bf16* src = wp_lane + ((size_t)(tap * a.ntn) * 4 + ks) * SPLIT * 1024;
 #pragma unroll
-    for (int u = 0; u < BV; ++u) r[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)(t + 256 * u) * 8);
+    for (int p = 0; p < SPLIT; ++p) r[p] = *reinterpret_cast<const bf16x8*>(src + p * 1024);
   };
-  auto store_b = [&](int buf, const bf16x8 (&r)[BV]) {
-    __bf16* Bb = Bs + (size_t)buf * SPLIT * BPL;
-#pragma unroll
-    for (int u = 0; u < BV; ++u) {
-      const int v = t + 256 * u, p = v >> 9, idx = v & 511, n = idx >> 3, k = (idx & 7) * 8;
-      *reinterpret_cast<bf16x8*>(Bb + p * BPL + n * LDK + k) = r[u];
-    }
-  };
-
-  load_b(0, breg[0]);
-  load_b(1, breg[1]);
+  if (!(a.debug & 8)) {
+    load_b(0, bq[0]);
+    load_b(1, bq[1]);
+  }
 
   // ---- halo patch: every (pixel, 4 channels) once; transform fused, split into planes, zeros outside the image / batch
-  {
+  if (!(a.debug & 1)) {
     const int per_img = a.halo_h * a.halo_w;
     const int total = a.halo_px * 16;
     const int c4 = (t & 15) * 4;
@@ -142,14 +137,12 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
       }
     }
   }
-  store_b(0, breg[0]);
-
   // ---- per-lane halo row of its A-fragment pixels (element offset inside a plane)
   const int tile_px = a.NI * a.TH * a.TW;
   int hbase[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    int p = wm * 64 + mi * 32 + li;
+    int p = wm * (32 * MI) + mi * 32 + li;
     if (p >= tile_px) p = 0;
     const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
     const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
@@ -164,51 +157,52 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
 
   __syncthreads();
 
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int buf = tap & 1;
-    if (tap + 2 < 9) load_b(tap + 2, breg[(tap + 2) % 3]);  // ring slot (tap + 2) % 3 was stored to LDS one tap ago
+  // 36 k-steps (9 taps x 4 blocks of 16 channels), no barrier: B two steps ahead from L2, A one step ahead from LDS
+  bf16x8 af[2][MI][SPLIT];
+  auto load_a = [&](int step, bf16x8 (&fa)[MI][SPLIT]) {
+    const int tap = step >> 2, ks = step & 3;
     const int kh = tap / 3, kw = tap - kh * 3;
     const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
-    const int tapoff = (dh * a.halo_w + dw) * LDK;
-    const __bf16* Bb = Bs + (size_t)buf * SPLIT * BPL + (wn * 32 + li) * LDK + 8 * lh;
+    const int off = (dh * a.halo_w + dw) * LDK + ks * 16;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[MI][SPLIT], bf[SPLIT];
+    for (int p = 0; p < SPLIT; ++p)
 #pragma unroll
-      for (int p = 0; p < SPLIT; ++p) {
-        bf[p] = *reinterpret_cast<const bf16x8*>(Bb + p * BPL + ks * 16);
+      for (int mi = 0; mi < MI; ++mi) fa[mi][p] = *reinterpret_cast<const bf16x8*>(As + p * a_plane + hbase[mi] + off);
+  };
+  if (!(a.debug & 4)) load_a(0, af[0]);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          af[mi][p] = *reinterpret_cast<const bf16x8*>(As + p * a_plane + hbase[mi] + tapoff + ks * 16);
-      }
+  for (int step = 0; step < 36; ++step) {
+    if (a.debug & 4) break;
+    const int cur = step & 1;
+    if (step + 2 < 36 && !(a.debug & 8)) load_b(step + 2, bq[(step + 2) % 3]);
+    if (step + 1 < 36) load_a(step + 1, af[cur ^ 1]);
+    const bf16x8 (&bf)[SPLIT] = bq[step % 3];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (SPLIT == 1) {
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], acc[mi], 0, 0, 0);
-        } else {
-          // smallest terms first
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SPLIT - 1], bf[0], acc[mi], 0, 0, 0);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[SPLIT - 1], acc[mi], 0, 0, 0);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[1], acc[mi], 0, 0, 0);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[0], acc[mi], 0, 0, 0);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[1], acc[mi], 0, 0, 0);
-          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], acc[mi], 0, 0, 0);
-        }
+    for (int mi = 0; mi < MI; ++mi) {
+      if (SPLIT == 1) {
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][0], bf[0], acc[mi], 0, 0, 0);
+      } else {
+        // smallest terms first
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][SPLIT - 1], bf[0], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][0], bf[SPLIT - 1], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][1], bf[1], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][1], bf[0], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][0], bf[1], acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi][0], bf[0], acc[mi], 0, 0, 0);
       }
     }
-    if (tap + 1 < 9) store_b(buf ^ 1, breg[(tap + 1) % 3]);
-    __syncthreads();
   }
+  __syncthreads();  // every wave is done with the patch: LDS becomes the output staging tile
 
   // ---- epilogue (as conv3x3_halo.hip): accumulators -> LDS tile [BM][68] floats -> 16-byte row stores
+  if (a.debug & 2) return;
   constexpr int LDO = 68;
   float* Os = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      Os[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
+      Os[(wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
   __syncthreads();
   const int c4 = (t & 15) * 4, col = co0 + c4;
   f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
@@ -273,7 +267,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(BfArgs a) {
 
 static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// ---- weight pre-split: Wp[tap][Cout tile][plane][n][k] = piece `plane` of w[tap][k][n] (any strides), zero beyond K / N
+// ---- weight pre-split: piece `plane` of w[tap][k][n] (any strides) in MFMA B-fragment order, zero beyond K / N
 struct BfPrepEntry {   // same 64 bytes as the Winograd entry of conv3x3_wino.hip (lvae_conv2d_prepare_entry); kind = planes (1 | 3)
   const float* w;
   __bf16* U;
@@ -290,10 +284,11 @@ __device__ __forceinline__ void bf_prep_element(const BfPrepEntry& e, int idx) {
   const int ntn = e.Npad >> 6, tn = n >> 6, nn = n & 63;
   for (int tap = 0; tap < 9; ++tap) {
     float r = (n < e.N && k < e.K) ? e.w[tap * e.stap + (int64_t)k * e.sk + (int64_t)n * e.sn] : 0.f;
-    __bf16* dst = e.U + ((size_t)(tap * ntn + tn) * e.kind) * 4096 + nn * 64 + k;
+    // fragment order: [tap][Cout tile][k-step][plane][n half][lane = (k % 16 / 8) * 32 + n % 32][k % 8]
+    __bf16* dst = e.U + ((size_t)((tap * ntn + tn) * 4 + (k >> 4)) * e.kind * 2 + (nn >> 5)) * 512 + (((k >> 3) & 1) * 32 + (nn & 31)) * 8 + (k & 7);
     for (int p = 0; p < e.kind; ++p) {
       const __bf16 b = (__bf16)r;
-      dst[(size_t)p * 4096] = b;
+      dst[(size_t)p * 1024] = b;
       r -= (float)b;
     }
   }
@@ -316,7 +311,7 @@ int conv3x3_bf16_prepare_batched(const void* entries, int n, int npad, hipStream
 
 size_t conv3x3_bf16_workspace(const lvae_conv_desc* d, int split) {
   const int ntn = (d->Cout + 63) / 64;
-  return (size_t)9 * ntn * split * 4096 * sizeof(__bf16);
+  return (size_t)9 * ntn * split * 4096 * sizeof(__bf16);  // 9 taps x Cout tiles x planes x (64 x 64)
 }
 
 void conv3x3_bf16_prep_entry(const lvae_conv_desc* d, int split, void* entry) {
@@ -335,20 +330,20 @@ void conv3x3_bf16_prep_entry(const lvae_conv_desc* d, int split, void* entry) {
   memcpy(entry, &e, sizeof(e));
 }
 
-static size_t bf_lds_bytes(int split, int halo_px) {
-  const size_t in = ((size_t)split * halo_px * BF_LDK + (size_t)2 * split * 64 * BF_LDK) * 2;
-  const size_t out = (size_t)BF_BM * 68 * 4;
+static size_t bf_lds_bytes(int split, int halo_px, int bm) {
+  const size_t in = (size_t)split * halo_px * BF_LDK * 2;
+  const size_t out = (size_t)bm * 68 * 4;
   return in > out ? in : out;
 }
 
 // tile geometry for a W-wide image (as conv3x3_halo.hip): rows per tile and images per tile so that NI*TH*W <= 128
-static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
+static bool bf_plan_bm(const lvae_conv_desc* d, int split, int BM, BfArgs& a) {
   const int N = d->N, H = d->H, W = d->W;
-  if (W > BF_BM) return false;
+  if (W > BM) return false;
   int TH = 1;
   for (int c = 1; c <= H; ++c)
-    if (H % c == 0 && c * W <= BF_BM) TH = c;
-  int NI = BF_BM / (TH * W);
+    if (H % c == 0 && c * W <= BM) TH = c;
+  int NI = BM / (TH * W);
   if (NI < 1) NI = 1;
   if (TH < H) NI = 1;
   if (NI > N) NI = N;
@@ -363,7 +358,15 @@ static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
   a.m_tw = fastdiv_magic(W);
   a.m_per_img = fastdiv_magic(a.halo_h * a.halo_w);
   a.m_halo_w = fastdiv_magic(a.halo_w);
-  return bf_lds_bytes(split, a.halo_px) <= 160 * 1024;
+  a.bm = BM;
+  return bf_lds_bytes(split, a.halo_px, BM) <= 160 * 1024;
+}
+
+// 128-pixel tiles when their patch leaves room for two workgroups per CU (<= 80 KB), else 64-pixel tiles
+static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
+  if (bf_plan_bm(d, split, 128, a) && bf_lds_bytes(split, a.halo_px, 128) <= 80 * 1024) return true;
+  if (bf_plan_bm(d, split, 64, a)) return true;
+  return bf_plan_bm(d, split, 128, a);
 }
 
 static bool bf_select(const lvae_conv_desc* d, int split, BfArgs& a) {
@@ -403,9 +406,9 @@ int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split) {
   return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
 }
 
-template <int SPLIT>
+template <int SPLIT, int MI>
 static int launch_bf(BfArgs a, hipStream_t s) {
-  auto kern = conv3x3_bf16_kernel<SPLIT>;
+  auto kern = conv3x3_bf16_kernel<SPLIT, MI>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -418,7 +421,7 @@ static int launch_bf(BfArgs a, hipStream_t s) {
   const int img_groups = (a.d.N + a.NI - 1) / a.NI;
   a.ntn = (a.d.Cout + 63) / 64;
   a.d.in_fold = nullptr;
-  hipLaunchKernelGGL(kern, dim3(img_groups * a.tiles_h * a.ntn), dim3(256), bf_lds_bytes(SPLIT, a.halo_px), s, a);
+  hipLaunchKernelGGL(kern, dim3(img_groups * a.tiles_h * a.ntn), dim3(256), bf_lds_bytes(SPLIT, a.halo_px, 64 * MI), s, a);
   LVAE_LAUNCH_CHECK("conv3x3_bf16");
   return 0;
 }
@@ -436,7 +439,11 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
     hipLaunchKernelGGL(bf_weight_kernel, dim3((e.Npad * 64 + 255) / 256), dim3(256), 0, s, e);
   }
   a.Wp = static_cast<const __bf16*>(d->workspace);
-  return split == 1 ? launch_bf<1>(a, s) : launch_bf<3>(a, s);
+  static const int dbg = lvae::debug_phase_switch("LVAE_BF16_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
+  a.debug = dbg;
+  a.ntn = (d->Cout + 63) / 64;
+  if (a.bm == 128) return split == 1 ? launch_bf<1, 2>(a, s) : launch_bf<3, 2>(a, s);
+  return split == 1 ? launch_bf<1, 1>(a, s) : launch_bf<3, 1>(a, s);
 }
 
 }  // namespace lvae
