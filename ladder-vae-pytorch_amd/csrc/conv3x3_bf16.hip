@@ -364,7 +364,9 @@ static bool bf_plan_bm(const lvae_conv_desc* d, int split, int BM, BfArgs& a) {
 
 // 128-pixel tiles when their patch leaves room for two workgroups per CU (<= 80 KB), else 64-pixel tiles
 static bool bf_plan(const lvae_conv_desc* d, int split, BfArgs& a) {
-  if (bf_plan_bm(d, split, 128, a) && bf_lds_bytes(split, a.halo_px, 128) <= 80 * 1024) return true;
+  if (bf_plan_bm(d, split, 128, a) && bf_lds_bytes(split, a.halo_px, 128) <= 80 * 1024 &&
+      (int64_t)((d->N + a.NI - 1) / a.NI) * a.tiles_h * ((d->Cout + 63) / 64) >= 256)  // ... and the grid still fills the chip
+    return true;
   if (bf_plan_bm(d, split, 64, a)) return true;
   return bf_plan_bm(d, split, 128, a);
 }
@@ -393,8 +395,12 @@ bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split) {
 // six-product split for the large fp32 layers (LVAE_F32_SPLIT=0 keeps them on the fp32 MFMA / Winograd kernels), 0 = neither.
 int conv3x3_bf16_form(const lvae_conv_desc* d) {
   if (d->precision == LVAE_PREC_BF16) return conv3x3_bf16_eligible(d, 1) ? 1 : 0;
-  const char* sw = getenv("LVAE_F32_SPLIT");  // A/B switch, read per call (the parity tests run both forms in one process)
-  const bool split_on = sw == nullptr || atoi(sw) != 0;
+  // Off by default: measured on MI355X (profiles/r02_conv3x3_forms.txt) the six-product form only ties Winograd-fp32 at 16x16
+  // (32.3 vs 31.1 us) and loses at 32x32 (122 vs 100 us): under a dense bf16-MFMA load the chip holds ~1.6 GHz, so 6/16 of the
+  // fp32-MFMA cycles is worth ~280 TFLOP/s fp32-equivalent against Winograd's 16/36 on the fp32 pipe. Read per call (the parity
+  // tests run both forms in one process).
+  const char* sw = getenv("LVAE_F32_SPLIT");
+  const bool split_on = sw != nullptr && atoi(sw) != 0;
   static const int64_t min_m = getenv("LVAE_F32_SPLIT_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_MIN_M")) : 256 * 64;  // tuning switch
   if (!split_on || (int64_t)d->N * d->H * d->W < min_m) return 0;
   return conv3x3_bf16_eligible(d, 3) ? 3 : 0;

@@ -75,6 +75,8 @@ def build_parser():
     # engine flags (new)
     p.add_argument('--synthetic', action='store_true', help='train on synthetic batches (no dataset files needed)')
     p.add_argument('--data-npz', type=str, default='', help="train on an .npz with key 'data' (N,C,H,W) float32 in [0,1]")
+    p.add_argument('--dtype', type=str, choices=['f32', 'bf16'], default='f32', dest='compute_dtype',
+                   help='bf16: bf16 matrix-core operands, fp32 accumulate / statistics / KL / likelihood')
     p.add_argument('--steps', type=int, default=0, help='stop after this many steps (0: --max-steps)')
     p.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
     p.add_argument('--log-every', type=int, default=100)
@@ -149,6 +151,7 @@ class LVAEExperiment:
                           img_shape=self.img_size, likelihood_form=a.likelihood, gated=a.gated,
                           no_initial_downscaling=a.no_initial_downscaling, analytical_kl=a.analytical_kl).to(self.device)
         model.noise = PhiloxNoise(seed=a.seed)
+        model.compute_dtype = a.compute_dtype
         return model
 
     def _make_optimizer(self):

@@ -108,6 +108,10 @@ class LadderVAE(nn.Module):
 
         self.noise = PhiloxNoise(seed=0)
         self.arena = None
+        # engine attribute (not a constructor argument of the reference): 'f32', or 'bf16' = bf16 matrix-core operands with fp32
+        # accumulation, statistics, KL and likelihood (the arithmetic of the reference under torch.autocast(bfloat16)) for the
+        # convolutions that have a bf16 kernel (lvae_conv2d_bf16); activations, parameters and gradients stay fp32 in HBM
+        self.compute_dtype = 'f32'
         self.grad_tracker = None  # dist.GradAllReduce when gradients are exchanged while backward runs (engine.TrainStep sets it)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -177,6 +181,7 @@ class LadderVAE(nn.Module):
 
     def _begin(self, ref_tensor, batch=None):
         self.pack(ref_tensor.device if ref_tensor is not None else None)
+        K.set_precision(self.compute_dtype)
         self.noise.begin(next(self.parameters()).device, self._mask_plan(batch) if batch else None)
 
     # ------------------------------------------------------------------------------------------------------------

@@ -54,7 +54,7 @@ def oracle_step(case):
     return _oracle[case]
 
 
-def run_engine(case, use_graph):
+def run_engine(case, use_graph, dtype='f32'):
     import lvae_amd  # noqa: F401
     from lvae_amd import kernels as K
     from lvae_amd.models.lvae import LadderVAE
@@ -65,6 +65,7 @@ def run_engine(case, use_graph):
     model = LadderVAE(**cfg)
     model.load_state_dict(init)
     model.cuda().train()
+    model.compute_dtype = dtype
     model.noise = TapeNoise(entries, loop=True)
     opt = Adamax(model, lr=0.0)                # lr 0: every step sees the same weights, so every step must match the oracle
     K.prepared.entries.clear()
@@ -98,7 +99,8 @@ def run_engine(case, use_graph):
             worst, worst_key = e, k
     K.prepared.entries.clear()
     K.prepared.table = None
-    rec = {'mode': 'graph' if use_graph else 'eager'}
+    K.set_precision('f32')
+    rec = {'mode': ('graph' if use_graph else 'eager') + ('' if dtype == 'f32' else '-' + dtype)}
     for k in ('loss', 'elbo', 'recons', 'kl', 'l2'):
         rec[k] = {'hip': res[k], 'oracle': scal[k], 'rel': abs(res[k] - scal[k]) / max(abs(scal[k]), 1e-30)}
     rec['kl_layer_max_abs'] = float((kl_layers - scal['kl_avg_layerwise']).abs().max())
@@ -128,3 +130,15 @@ def test_full_training_step_matches_oracle(case, use_graph):
     assert rec['kl_layer_max_rel'] <= 1e-5 or rec['kl_layer_max_abs'] <= 1e-4, rec
     assert rec['grad_worst_rel_l2'] <= 1e-4, (rec['grad_worst_key'], rec['grad_worst_rel_l2'])
     assert rec['gradnorm']['rel'] <= 1e-6, rec['gradnorm']
+
+
+def test_bf16_training_step_is_within_the_stated_tolerance_of_the_fp32_oracle():
+    """BASELINE configs[3] per-GPU shard (CIFAR10 15-layer, batch 256) with compute_dtype = 'bf16' (bf16 matrix-core operands in the
+    3x3 convolutions of the 8x8 .. 32x32 levels, everything else fp32): SURVEY.md §8(c) asks elbo relative <= 1e-2 against the
+    fp32 oracle on the same weights, input and noise tape."""
+    rec = run_engine('cfg3_cifar15_b256', True, dtype='bf16')
+    for k in ('loss', 'elbo', 'recons'):
+        assert rec[k]['rel'] <= 1e-2, (k, rec[k])
+    assert rec['kl']['rel'] <= 5e-2, rec['kl']                # KL is the small difference of large terms (2.9e3 of 2.2e4)
+    assert rec['gradnorm']['rel'] <= 5e-2, rec['gradnorm']
+    assert rec['grad_worst_rel_l2'] > 1e-4                      # ... and it really ran in reduced precision
