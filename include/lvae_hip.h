@@ -16,7 +16,7 @@
  *    kernel (an idempotent hipFuncSetAttribute on first use). Read-only process state: the tuning / A-B switches below, each read
  *    from the environment once on first use; every value selects among kernel variants that pass the same parity tests:
  *      LVAE_DISABLE_WINO, LVAE_DISABLE_WINO_WGRAD, LVAE_DISABLE_HALO, LVAE_DISABLE_W1X1   (fall back to the direct kernels)
- *      LVAE_F32_SPLIT (1: run the large fp32 3x3 layers as six exact bf16-piece products on the bf16 MFMA instead of Winograd-fp32), LVAE_DISABLE_POS,
+ *      LVAE_F32_SPLIT (1: run the large fp32 3x3 layers as six exact bf16-piece products on the bf16 MFMA instead of Winograd-fp32), LVAE_DISABLE_POS, LVAE_DISABLE_GATE_FUSED, LVAE_GATE_FUSED_MIN_M,
  *      LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
  *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
  *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 7
+#define LVAE_ABI_VERSION 8
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -168,6 +168,17 @@ int32_t lvae_conv1x1_gate_stats_rows(const lvae_conv_desc* d);
  * Same shape limits as lvae_conv1x1_gate_f32, otherwise LVAE_EINVAL (compose lvae_gate_bwd_f32 + lvae_conv2d_f32). */
 int lvae_conv1x1_gate_bwd_f32(const lvae_conv_desc* d, const float* dout, const float* ab, int32_t act, float* dab,
                               void* stream);
+
+/* GateLayer2d backward of a 64-channel block as ONE persistent kernel: gate derivative + input gradient (exactly
+ * lvae_conv1x1_gate_bwd_f32, same descriptor) AND the weight / bias gradient of the gate convolution, dw[ci*dw_sk + co*dw_sn] +=
+ * sum_m y[m,ci] * dab[m,co], db[co] += sum_m dab[m,co] (autograd of lib/nn.py:118-126): dab is formed once per 64-pixel tile in LDS and
+ * never written to memory; y [M,64] is the convolution input the forward saved. Deterministic (per-workgroup partial slabs in
+ * `workspace`, summed in a fixed order). lvae_conv1x1_gate_bwd_wgrad_workspace(d) == 0: shape not supported (needs C = 64 and at
+ * least 16384 pixels) — use lvae_conv1x1_gate_bwd_f32 + lvae_conv2d_wgrad_f32. */
+size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d);
+int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
+                                    float* dw, int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, size_t workspace_bytes,
+                                    void* stream);
 
 /* Weight / bias gradient of the convolution described by `d` (d->y is unused, d->w gives only the strides):
  *   dw[tap,k,n] += sum_{n,oh,ow} T(x)[n,ih,iw,k] * dy[n,oh,ow,n]     db[n] += sum dy[..,n]

@@ -1,0 +1,241 @@
+// GateLayer2d backward for C = 64 as ONE persistent kernel: gate derivative, input gradient of the 1x1 convolution AND its weight /
+// bias gradient (autograd of lib/nn.py:118-126 of the reference).
+//
+//   dab[m, c]     = dout[m, c] * sigmoid(b) * act'(a)            (a, b = the halves of the saved pre-activations ab [M, 128])
+//   dab[m, 64+c]  = dout[m, c] * act(a) * sigmoid(b) * (1 - sigmoid(b))
+//   dx[m, ci]     = (sum_co dab[m, co] * W[co, ci]) * drop[n(m), ci]
+//   dW[co, ci]   += sum_m  y[m, ci] * dab[m, co]                 (y = the convolution input saved by the forward)     db[co] += sum_m dab[m, co]
+//
+// Before, this was two launches and three passes over memory: the fused gate-backward + dgrad kernel wrote dab (33.5 MB at
+// 256x16x16) for the weight-gradient kernel, which read it back together with y. Here dab lives only in LDS: a workgroup loops
+// over 64-pixel tiles (persistent, one per CU), forms dab once, uses it as the A operand of the dgrad GEMM and as the B operand of
+// the weight-gradient GEMM, whose 64 x 128 accumulator stays in registers across all tiles of the workgroup; the raw operands of
+// the next tile are prefetched into registers while the current tile's 128 MFMAs per wave run. HBM traffic per gated block drops
+// from 150 MB to 84 MB and one launch disappears. Per-workgroup weight-gradient partials go to the usual split-K slabs
+// ([workgroup][64][128] + [workgroup][128]) and are summed in a fixed order (wgrad_reduce_launch): deterministic.
+#include "lvae_common.h"
+
+namespace lvae {
+
+void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
+                         int64_t sn, float* dw, float* db, hipStream_t s);
+
+struct GbfArgs {
+  const float* dout;   // [M][64]
+  const float* ab;     // [M][128]
+  const float* y;      // [M][64]
+  const float* w;      // element (k = co, n = ci) at w[k*w_sk + n*w_sn], w_sk == 1 (k-contiguous rows of 128)
+  int64_t w_sn;
+  const float* drop;   // [N][64] or null
+  float* dx;           // [M][64]
+  float* slab_w;       // [nwg][64 ci][128 co]
+  float* slab_b;       // [nwg][128] or null
+  int M, ohw, ntiles, act;
+};
+
+constexpr int GB_LDA = 132;  // dab / weight row pitch (floats): conflict-free ds_read_b128 (as conv1x1.hip)
+constexpr int GB_LDY = 68;   // y / dx staging row pitch
+
+__global__ __launch_bounds__(256) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                       // [64 ci][132]: W[co][ci] as B[k = co][n = ci], k-contiguous
+  float* As = Bs + 64 * GB_LDA;           // [64 px][132]: dab tile (A of the dgrad, B of the weight gradient); later dx staging
+  float* Ys = As + 64 * GB_LDA;           // [64 px][68]: y tile (A^T of the weight gradient)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- weights once per workgroup
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = t + 256 * u, n = idx >> 5, k = (idx & 31) * 4;
+    *reinterpret_cast<f32x4*>(Bs + n * GB_LDA + k) = *reinterpret_cast<const f32x4*>(a.w + (int64_t)n * a.w_sn + k);
+  }
+
+  // ---- raw operands of one tile: thread -> 4 items (row r = idx / 16, channels c = (idx % 16) * 4) of dout, a, b and y
+  f32x4 pg[4], pa[4], pb[4], py[4];
+  const int c4 = (t & 15) * 4, r0 = t >> 4;
+  auto prefetch = [&](int tile) {
+    const int m0 = tile * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + r0 + 16 * u;
+      const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
+      pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
+      pa[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + c4);
+      pb[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + 64 + c4);
+      py[u] = *reinterpret_cast<const f32x4*>(a.y + mc * 64 + c4);
+    }
+  };
+
+  // weight-gradient accumulators of this wave: ci block (wave & 1), co blocks 2 * (wave >> 1) + {0, 1}
+  f32x16 accw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+  f32x4 bs_lo = zero4, bs_hi = zero4;  // bias-gradient partials of this thread's channels (c4.. and 64 + c4..)
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int m0 = tile * 64;
+    // ---- gate derivative from the prefetched registers -> LDS (dab tile, y tile)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 16 * u;
+      f32x4 lo = zero4, hi = zero4, yv = zero4;
+      if (m0 + r < a.M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(pb[u][j]);
+          lo[j] = pg[u][j] * sg * act_grad(pa[u][j], a.act);
+          hi[j] = pg[u][j] * act_fwd(pa[u][j], a.act) * sg * (1.f - sg);
+        }
+        yv = py[u];
+      }
+      bs_lo += lo;
+      bs_hi += hi;
+      *reinterpret_cast<f32x4*>(As + r * GB_LDA + c4) = lo;
+      *reinterpret_cast<f32x4*>(As + r * GB_LDA + 64 + c4) = hi;
+      *reinterpret_cast<f32x4*>(Ys + r * GB_LDY + c4) = yv;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);  // in flight during the 128 MFMAs below
+
+    // ---- dgrad: dx[32 px (wm)][32 ci (wn)] = dab[px][0:128] . W
+    f32x16 accx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 128; kk += 8) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(As + (wm * 32 + li) * GB_LDA + kk + 4 * lh);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + li) * GB_LDA + kk + 4 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], accx, 0, 0, 0);
+    }
+    // ---- weight gradient: dW[32 ci (wn)][2 x 32 co (wm)] += y^T . dab over the 64 pixels of the tile (k = pixel)
+#pragma unroll 8
+    for (int p = 0; p < 64; p += 2) {
+      const float ya = Ys[(p + lh) * GB_LDY + wn * 32 + li];
+      const float b0 = As[(p + lh) * GB_LDA + (wm * 2) * 32 + li];
+      const float b1 = As[(p + lh) * GB_LDA + (wm * 2 + 1) * 32 + li];
+      accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b0, accw[0], 0, 0, 0);
+      accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b1, accw[1], 0, 0, 0);
+    }
+    __syncthreads();  // dab / y tiles are dead: the dab region becomes the dx staging tile [64][68]
+
+    float* Os = As;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 16 * u, m = m0 + r;
+      if (m < a.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
+        if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
+        *reinterpret_cast<f32x4*>(a.dx + (size_t)m * 64 + c4) = v;
+      }
+    }
+    __syncthreads();  // staging tile is read: the next iteration overwrites it
+  }
+
+  // ---- this workgroup's weight / bias gradient partials -> slabs (128-byte row segments straight from the accumulators)
+  float* sw = a.slab_w + (size_t)blockIdx.x * 64 * 128;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      sw[(size_t)(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + (wm * 2 + j) * 32 + li] = accw[j][r];
+  if (a.slab_b) {
+    float* red = Ys;  // [16 row groups][128]
+    *reinterpret_cast<f32x4*>(red + r0 * 128 + c4) = bs_lo;
+    *reinterpret_cast<f32x4*>(red + r0 * 128 + 64 + c4) = bs_hi;
+    __syncthreads();
+    if (t < 128) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += red[g * 128 + t];
+      a.slab_b[(size_t)blockIdx.x * 128 + t] = v;
+    }
+  }
+}
+
+static bool al16f(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// workgroups (= weight-gradient slabs) for M pixels: one per CU, fewer when there are fewer tiles
+static int gbf_nwg(int64_t M) {
+  const int64_t ntiles = (M + 63) / 64;
+  return (int)(ntiles < 256 ? ntiles : 256);
+}
+
+// `d` describes the dgrad of the gate convolution exactly as for lvae_conv1x1_gate_bwd_f32 (C1 = 2C = 128, Cout = C = 64, weight
+// strides of the transposed view, y = dx, out_scale = dropout mask). 0 when this kernel does not take the shape.
+size_t conv1x1_gate_bwd_fused_workspace(const lvae_conv_desc* d) {
+  static const bool off = getenv("LVAE_DISABLE_GATE_FUSED") != nullptr;  // A/B switch, profiling only
+  if (off || d == nullptr) return 0;
+  if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->C1 != 128 || d->C2 != 0 || d->Cout != 64 || d->w_sk != 1 || d->w_sn % 4 != 0 || d->in_scale != nullptr) return 0;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  static const int64_t min_m = getenv("LVAE_GATE_FUSED_MIN_M") ? atoll(getenv("LVAE_GATE_FUSED_MIN_M")) : 256 * 64;  // tuning switch
+  if (M < min_m || M >= ((int64_t)1 << 31)) return 0;
+  return (size_t)gbf_nwg(M) * (64 * 128 + 128) * sizeof(float);
+}
+
+int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int act, float* dw,
+                           int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, hipStream_t s) {
+  if (!al16f(dout) || !al16f(ab) || !al16f(y) || !al16f(d->w) || !al16f(d->y) || !al16f(d->out_scale) || !al16f(workspace)) return -1000;
+  GbfArgs a;
+  a.dout = dout;
+  a.ab = ab;
+  a.y = y;
+  a.w = d->w;
+  a.w_sn = d->w_sn;
+  a.drop = d->out_scale;
+  a.dx = d->y;
+  a.M = d->N * d->H * d->W;
+  a.ohw = d->H * d->W;
+  a.ntiles = (a.M + 63) / 64;
+  a.act = act;
+  const int nwg = gbf_nwg(a.M);
+  a.slab_w = static_cast<float*>(workspace);
+  a.slab_b = db ? a.slab_w + (size_t)nwg * 64 * 128 : nullptr;
+  constexpr size_t lds = (size_t)(2 * 64 * GB_LDA + 64 * GB_LDY) * sizeof(float);
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv1x1_gate_bwd_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(256), lds, s, a);
+  LVAE_LAUNCH_CHECK("conv1x1_gate_bwd_fused");
+  // slabs are [nwg][ci][co]: the gate convolution's weight element (ci, co) lives at dw[ci * dw_sk + co * dw_sn]
+  wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 1, 64, 128, 0, dw_sk, dw_sn, dw, db, s);
+  LVAE_LAUNCH_CHECK("conv1x1_gate_bwd_fused_reduce");
+  return 0;
+}
+
+}  // namespace lvae
+
+using namespace lvae;
+
+extern "C" size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d) { return conv1x1_gate_bwd_fused_workspace(d); }
+
+extern "C" int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
+                                               float* dw, int64_t dw_sk, int64_t dw_sn, float* db, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  LVAE_REQUIRE(d && dout && ab && y && d->y && dw && workspace, LVAE_EINVAL, "lvae_conv1x1_gate_bwd_wgrad_f32: null pointer");
+  const size_t need = conv1x1_gate_bwd_fused_workspace(d);
+  LVAE_REQUIRE(need > 0, LVAE_EINVAL,
+               "lvae_conv1x1_gate_bwd_wgrad_f32: unsupported shape (needs the gate of a 64-channel block: 1x1, 128 -> 64 dgrad view, at "
+               "least 16384 pixels); use lvae_conv1x1_gate_bwd_f32 + lvae_conv2d_wgrad_f32");
+  LVAE_REQUIRE(workspace_bytes >= need, LVAE_EWORKSPACE, "lvae_conv1x1_gate_bwd_wgrad_f32: workspace %zu < %zu", workspace_bytes, need);
+  const int rc = conv1x1_gate_bwd_fused(d, dout, ab, y, act, dw, dw_sk, dw_sn, db, workspace, (hipStream_t)stream);
+  LVAE_REQUIRE(rc != -1000, LVAE_EALIGN, "lvae_conv1x1_gate_bwd_wgrad_f32: buffers must be 16-byte aligned");
+  return rc;
+}

@@ -318,6 +318,26 @@ def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):
     return dab, dx
 
 
+def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scale=None):
+    """conv1x1_gate_bwd and the weight / bias gradient of the gate convolution in one persistent kernel (dab never leaves LDS):
+    returns dx, and accumulates into dweight / dbias. Returns None when the shape is not supported (caller composes the two)."""
+    _chk_nhwc(dout, 'dout')
+    N, H, W, Cn = dout.shape
+    if not (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cout == 2 * Cn and g.s_co == 1):
+        return None
+    if tuple(dweight.stride()) != tuple(weight.stride()):
+        return None
+    dx = torch.empty((N, H, W, g.Cin), dtype=torch.float32, device=dout.device)
+    d = _desc(g, weight, ab, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
+    need = _C.load().lvae_conv1x1_gate_bwd_wgrad_workspace(C.byref(d))
+    if not need:
+        return None
+    ws = workspace(need, dout.device)
+    call('lvae_conv1x1_gate_bwd_wgrad_f32', C.byref(d), ptr(dout), ptr(ab), ptr(y), ACT[act], ptr(dweight), g.s_ci, g.s_co, ptr(dbias),
+         ws.data_ptr(), ws.numel(), stream_ptr())
+    return dx
+
+
 def bn_coef_block(scale, shift, mean, rstd):
     """True when the four coefficient vectors are consecutive rows of one buffer (as bn_stats / bn_finalize_parts return them)."""
     if scale is None or shift is None or mean is None or rstd is None:

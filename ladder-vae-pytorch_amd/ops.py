@@ -226,8 +226,13 @@ class ResBlockFn(Function):
         hw = (x.shape[1], x.shape[2])
         if blk.gate is not None:
             gw = blk.gate.weight
-            dab, dy2 = K.conv1x1_gate_bwd(dout, ab, gw, blk.gate.geom(), act, out_scale=m2)
-            wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
+            dy2 = None
+            if gw.requires_grad and blk.gate.bias is not None:
+                # large levels: gate derivative, dgrad and the gate convolution's weight gradient in one persistent kernel
+                dy2 = K.conv1x1_gate_bwd_wgrad(dout, ab, y2, gw, blk.gate.geom(), act, grad_buf(gw), grad_buf(blk.gate.bias), out_scale=m2)
+            if dy2 is None:
+                dab, dy2 = K.conv1x1_gate_bwd(dout, ab, gw, blk.gate.geom(), act, out_scale=m2)
+                wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
         else:
             dy2 = K.scale_rows_add(dout, m2, None) if m2 is not None else dout
         # second half

@@ -676,3 +676,33 @@ def test_conv3x3_bf16_operands(K, case):
     if dx is not None:
         dref = F.conv_transpose2d(bf(dy).double(), bf(w).double(), padding=1).float()
         assert rel(nchw(dx), dref) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(256, 16, 16), (70, 16, 16), (33, 32, 32), (257, 8, 8)])
+def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape):
+    """lvae_conv1x1_gate_bwd_wgrad_f32 (gate derivative + dgrad + weight / bias gradient of the gate convolution, one persistent
+    kernel) == autograd of lib/nn.py:118-126, accumulating into non-zero gradient buffers."""
+    N, H, W = shape
+    C = 64
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C)).requires_grad_(True)
+    b = torch.randn(2 * C, generator=g).requires_grad_(True)
+    ab = F.conv2d(x, w, b)
+    a_, b_ = ab.chunk(2, 1)
+    out = F.elu(a_) * torch.sigmoid(b_)
+    dout = torch.randn(out.shape, generator=g)
+    mask = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
+    out.backward(dout)
+    wp = packed_weight(w.detach())
+    geom = K.ConvGeom(wp, 1, 0)
+    dw0, db0 = torch.randn(2 * C, C, 1, 1, generator=g) * 0.1, torch.randn(2 * C, generator=g)
+    dw, db = packed_weight(dw0), db0.cuda()
+    dx = K.conv1x1_gate_bwd_wgrad(nhwc(dout), nhwc(ab.detach()), nhwc(x.detach()), wp, geom, 'elu', dw, db, out_scale=mask.cuda())
+    assert dx is not None, "shape is meant to take the fused kernel"
+    assert rel(nchw(dx), x.grad * mask.view(N, C, 1, 1)) < 3e-6
+    assert rel(dw.cpu() - dw0, w.grad) < 5e-6
+    assert rel(db.cpu() - db0, b.grad) < 5e-6
+    # small layers are not taken (the caller composes gate_bwd + wgrad)
+    small = K.conv1x1_gate_bwd_wgrad(nhwc(dout[:4]), nhwc(ab.detach()[:4]), nhwc(x.detach()[:4]), wp, geom, 'elu', dw, db) if H * W * 4 < 16384 else None
+    assert small is None
