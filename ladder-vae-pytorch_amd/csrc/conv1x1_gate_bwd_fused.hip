@@ -9,8 +9,9 @@
 // Before, this was two launches and three passes over memory: the fused gate-backward + dgrad kernel wrote dab (33.5 MB at
 // 256x16x16) for the weight-gradient kernel, which read it back together with y. Here dab lives only in LDS: a workgroup loops
 // over 64-pixel tiles (persistent, one per CU), forms dab once, uses it as the A operand of the dgrad GEMM and as the B operand of
-// the weight-gradient GEMM, whose 64 x 128 accumulator stays in registers across all tiles of the workgroup; the raw operands of
-// the next tile are prefetched into registers while the current tile's 128 MFMAs per wave run. HBM traffic per gated block drops
+// the weight-gradient GEMM, whose 64 x 128 accumulator stays in registers across all tiles of the workgroup. Eight waves: waves
+// 0-3 run the dgrad GEMM of a tile while waves 4-7 run its weight-gradient GEMM (two waves per SIMD cover each other's LDS latency;
+// both read the same dab tile); the raw operands of the next tile are prefetched into registers while the MFMAs run. HBM traffic per gated block drops
 // from 150 MB to 84 MB and one launch disappears. Per-workgroup weight-gradient partials go to the usual split-K slabs
 // ([workgroup][64][128] + [workgroup][128]) and are summed in a fixed order (wgrad_reduce_launch): deterministic.
 #include "lvae_common.h"
@@ -36,30 +37,32 @@ struct GbfArgs {
 constexpr int GB_LDA = 132;  // dab / weight row pitch (floats): conflict-free ds_read_b128 (as conv1x1.hip)
 constexpr int GB_LDY = 68;   // y / dx staging row pitch
 
-__global__ __launch_bounds__(256) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) {
+__global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                       // [64 ci][132]: W[co][ci] as B[k = co][n = ci], k-contiguous
   float* As = Bs + 64 * GB_LDA;           // [64 px][132]: dab tile (A of the dgrad, B of the weight gradient); later dx staging
   float* Ys = As + 64 * GB_LDA;           // [64 px][68]: y tile (A^T of the weight gradient)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const bool wg_role = wave >= 4;  // waves 4-7: weight gradient; waves 0-3: dgrad
+  const int wm = (wave & 3) >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- weights once per workgroup
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int idx = t + 256 * u, n = idx >> 5, k = (idx & 31) * 4;
+  for (int u = 0; u < 4; ++u) {
+    const int idx = t + 512 * u, n = idx >> 5, k = (idx & 31) * 4;
     *reinterpret_cast<f32x4*>(Bs + n * GB_LDA + k) = *reinterpret_cast<const f32x4*>(a.w + (int64_t)n * a.w_sn + k);
   }
 
-  // ---- raw operands of one tile: thread -> 4 items (row r = idx / 16, channels c = (idx % 16) * 4) of dout, a, b and y
-  f32x4 pg[4], pa[4], pb[4], py[4];
+  // ---- raw operands of one tile: thread -> 2 items (row r = idx / 16, channels c = (idx % 16) * 4) of dout, a, b and y
+  constexpr int IT = 2;
+  f32x4 pg[IT], pa[IT], pb[IT], py[IT];
   const int c4 = (t & 15) * 4, r0 = t >> 4;
   auto prefetch = [&](int tile) {
     const int m0 = tile * 64;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m = m0 + r0 + 16 * u;
+    for (int u = 0; u < IT; ++u) {
+      const int m = m0 + r0 + 32 * u;
       const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
       pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
       pa[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + c4);
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
     const int m0 = tile * 64;
     // ---- gate derivative from the prefetched registers -> LDS (dab tile, y tile)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = r0 + 16 * u;
+    for (int u = 0; u < IT; ++u) {
+      const int r = r0 + 32 * u;
       f32x4 lo = zero4, hi = zero4, yv = zero4;
       if (m0 + r < a.M) {
 #pragma unroll
@@ -103,35 +106,40 @@ __global__ __launch_bounds__(256) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);  // in flight during the 128 MFMAs below
 
-    // ---- dgrad: dx[32 px (wm)][32 ci (wn)] = dab[px][0:128] . W
     f32x16 accx;
+    if (!wg_role) {
+      // ---- dgrad (waves 0-3): dx[32 px (wm)][32 ci (wn)] = dab[px][0:128] . W
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+      for (int r = 0; r < 16; ++r) accx[r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 128; kk += 8) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(As + (wm * 32 + li) * GB_LDA + kk + 4 * lh);
-      const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + li) * GB_LDA + kk + 4 * lh);
+      for (int kk = 0; kk < 128; kk += 8) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(As + (wm * 32 + li) * GB_LDA + kk + 4 * lh);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + li) * GB_LDA + kk + 4 * lh);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], accx, 0, 0, 0);
-    }
-    // ---- weight gradient: dW[32 ci (wn)][2 x 32 co (wm)] += y^T . dab over the 64 pixels of the tile (k = pixel)
+        for (int j = 0; j < 4; ++j) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], accx, 0, 0, 0);
+      }
+    } else {
+      // ---- weight gradient (waves 4-7): dW[32 ci (wn)][2 x 32 co (wm)] += y^T . dab over the 64 pixels of the tile (k = pixel)
 #pragma unroll 8
-    for (int p = 0; p < 64; p += 2) {
-      const float ya = Ys[(p + lh) * GB_LDY + wn * 32 + li];
-      const float b0 = As[(p + lh) * GB_LDA + (wm * 2) * 32 + li];
-      const float b1 = As[(p + lh) * GB_LDA + (wm * 2 + 1) * 32 + li];
-      accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b0, accw[0], 0, 0, 0);
-      accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b1, accw[1], 0, 0, 0);
+      for (int p = 0; p < 64; p += 2) {
+        const float ya = Ys[(p + lh) * GB_LDY + wn * 32 + li];
+        const float b0 = As[(p + lh) * GB_LDA + (wm * 2) * 32 + li];
+        const float b1 = As[(p + lh) * GB_LDA + (wm * 2 + 1) * 32 + li];
+        accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b0, accw[0], 0, 0, 0);
+        accw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, b1, accw[1], 0, 0, 0);
+      }
     }
     __syncthreads();  // dab / y tiles are dead: the dab region becomes the dx staging tile [64][68]
 
     float* Os = As;
+    if (!wg_role) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
+      for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
+    }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = r0 + 16 * u, m = m0 + r;
+    for (int u = 0; u < IT; ++u) {
+      const int r = r0 + 32 * u, m = m0 + r;
       if (m < a.M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
         if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
@@ -143,20 +151,22 @@ __global__ __launch_bounds__(256) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
 
   // ---- this workgroup's weight / bias gradient partials -> slabs (128-byte row segments straight from the accumulators)
   float* sw = a.slab_w + (size_t)blockIdx.x * 64 * 128;
+  if (wg_role) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      sw[(size_t)(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + (wm * 2 + j) * 32 + li] = accw[j][r];
+      for (int r = 0; r < 16; ++r)
+        sw[(size_t)(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + (wm * 2 + j) * 32 + li] = accw[j][r];
+  }
   if (a.slab_b) {
-    float* red = Ys;  // [16 row groups][128]
+    float* red = As;  // [32 row groups][128] (16 KB; every tile is done)
     *reinterpret_cast<f32x4*>(red + r0 * 128 + c4) = bs_lo;
     *reinterpret_cast<f32x4*>(red + r0 * 128 + 64 + c4) = bs_hi;
     __syncthreads();
     if (t < 128) {
       float v = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v += red[g * 128 + t];
+      for (int g = 0; g < 32; ++g) v += red[g * 128 + t];
       a.slab_b[(size_t)blockIdx.x * 128 + t] = v;
     }
   }
@@ -212,7 +222,7 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
   LVAE_LAUNCH_CHECK("conv1x1_gate_bwd_fused");
   // slabs are [nwg][ci][co]: the gate convolution's weight element (ci, co) lives at dw[ci * dw_sk + co * dw_sn]
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 1, 64, 128, 0, dw_sk, dw_sn, dw, db, s);
