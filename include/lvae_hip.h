@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 8
+#define LVAE_ABI_VERSION 9
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -256,6 +256,10 @@ int lvae_gate_bwd_f32(const float* dout, const float* ab, int64_t M, int32_t C, 
 /* y = act(x) in place-capable; dact: dx = dy * act'(x) expressed from the OUTPUT y (elu/relu/leaky/selu allow it) */
 int lvae_act_bwd_from_out_f32(const float* dy, const float* y, int64_t n, int32_t act, float* dx, void* stream);
 int lvae_add_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* out = (a + b) + c — the gradient of an activation with three consumers (TopDownLayer input: models/lvae_layers.py:134-160). */
+int lvae_add3_f32(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+/* out[0] = sum_l mean_n x[l][n] — `logp` of models/lvae.py:301 from the [L][N] matrix of per-layer, per-sample log p(z). */
+int lvae_sum_of_row_means_f32(const float* x, int32_t L, int32_t N, float* out, void* stream);
 /* residual without gate (lib/nn.py:99 when gated is falsy): out = (a*rowscale) + b */
 int lvae_scale_rows_add_f32(const float* a, const float* row_scale, int64_t rows_per_n, int32_t C, const float* b,
                             int64_t M, float* out, void* stream);

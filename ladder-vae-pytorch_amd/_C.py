@@ -42,7 +42,7 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 8  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 9  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -78,6 +78,8 @@ SIGNATURES = {
     'lvae_gate_bwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'lvae_act_bwd_from_out_f32': (C.c_int, [_P, _P, _L, _I, _P, _P]),
     'lvae_add_f32': (C.c_int, [_P, _P, _L, _P, _P]),
+    'lvae_add3_f32': (C.c_int, [_P, _P, _P, _L, _P, _P]),
+    'lvae_sum_of_row_means_f32': (C.c_int, [_P, _I, _I, _P, _P]),
     'lvae_scale_rows_add_f32': (C.c_int, [_P, _P, _L, _I, _P, _L, _P, _P]),
     'lvae_colsum_f32': (C.c_int, [_P, _L, _L, _P, _I, _P]),
     'lvae_normal_stochastic_fwd_f32': (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -457,6 +457,25 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
+// out = (a + b) + c: gradient of a tensor with three consumers, one pass instead of two
+__global__ __launch_bounds__(256) void add3_kernel(const float* a, const float* b, const float* c, int64_t n, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (a[i] + b[i]) + c[i];
+}
+
+// out[0] = sum_l mean_n x[l][n]  (logp of models/lvae.py:301: the sum over layers of the batch-mean log p(z_l)); one workgroup,
+// fixed summation order
+__global__ __launch_bounds__(256) void sum_of_row_means_kernel(const float* __restrict__ x, int L, int N, float* out) {
+  __shared__ float red[4];
+  float tot = 0.f;
+  for (int l = 0; l < L; ++l) {
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) s += x[(size_t)l * N + n];
+    s = block_sum_256(s, red);
+    tot += s / (float)N;
+  }
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
 __global__ __launch_bounds__(256) void scale_rows_add_kernel(const float* a, const float* row_scale, int64_t rows_per_n,
                                                               int C, const float* b, int64_t total, float* out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -695,6 +714,20 @@ extern "C" int lvae_add_f32(const float* a, const float* b, int64_t n, float* ou
   LVAE_REQUIRE(a && b && out && n > 0, LVAE_EINVAL, "lvae_add_f32: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
   LVAE_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int lvae_add3_f32(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream) {
+  LVAE_REQUIRE(a && b && c && out && n > 0, LVAE_EINVAL, "lvae_add3_f32: bad args");
+  hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, out);
+  LVAE_LAUNCH_CHECK("add3");
+  return 0;
+}
+
+extern "C" int lvae_sum_of_row_means_f32(const float* x, int32_t L, int32_t N, float* out, void* stream) {
+  LVAE_REQUIRE(x && out && L > 0 && N > 0, LVAE_EINVAL, "lvae_sum_of_row_means_f32: bad args");
+  hipLaunchKernelGGL(sum_of_row_means_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, L, N, out);
+  LVAE_LAUNCH_CHECK("sum_of_row_means");
   return 0;
 }
 

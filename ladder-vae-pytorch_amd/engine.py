@@ -27,8 +27,7 @@ def linear_anneal(step, start, end, steps):
 def forward_pass(model, x, beta=1.0, compute_l2=True):
     """LVAEExperiment.forward_pass (experiment/experiment_manager.py:322-367) on the HIP engine."""
     mo = model(x)
-    elbo_sep, scal = ops.ElboLossFn.apply(mo['ll'], mo['kl_sep'], mo['kl_loss'], float(beta))
-    loss, elbo, recons = scal.unbind(0)
+    elbo_sep, loss, elbo, recons = ops.ElboLossFn.apply(mo['ll'], mo['kl_sep'], mo['kl_loss'], float(beta))
     out = {'loss': loss, 'elbo': elbo, 'elbo_sep': elbo_sep, 'kl': mo['kl'], 'recons': recons,
            'out_mean': mo['out_mean'], 'out_mode': mo['out_mode'], 'out_sample': mo['out_sample'],
            'likelihood_params': mo['likelihood_params'], 'kl_avg_layerwise': mo['kl_avg_layerwise']}

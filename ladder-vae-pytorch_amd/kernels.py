@@ -512,6 +512,36 @@ def add(a, b):
     return out
 
 
+def fill_zero(t):
+    """zero a (small) tensor with our own kernel: out = 0 * out is not safe for NaN garbage, so scale_rows_add of a cached zero"""
+    z = _zeros_like_cached(t)
+    call('lvae_scale_rows_add_f32', ptr(z), None, 1, 1, None, t.numel(), ptr(t), stream_ptr())
+    return t
+
+
+_zero_cache = {}
+
+
+def _zeros_like_cached(t):
+    key = (t.device, t.numel())
+    if key not in _zero_cache:
+        _zero_cache[key] = torch.zeros(t.numel(), dtype=torch.float32, device=t.device)
+    return _zero_cache[key]
+
+
+def add3(a, b, c):
+    out = torch.empty_like(a)
+    call('lvae_add3_f32', ptr(a), ptr(b), ptr(c), a.numel(), ptr(out), stream_ptr())
+    return out
+
+
+def sum_of_row_means(x_ln):
+    L, N = x_ln.shape
+    out = torch.empty((1,), dtype=torch.float32, device=x_ln.device)
+    call('lvae_sum_of_row_means_f32', ptr(x_ln), L, N, ptr(out), stream_ptr())
+    return out
+
+
 def scale_rows_add(a, row_scale, b, out=None):
     """out = a * row_scale[n, c] + b  (either optional; with neither it is a device copy into `out`)."""
     Cn = a.shape[-1]
@@ -528,13 +558,16 @@ def colsum(x2d, out, accumulate):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def normal_stochastic_fwd(p, q, eps_or_z, mode, analytical_kl, Z, N):
-    """p (N|1,H,W,2Z), q (N,H,W,2Z)|None. Returns z (N,H,W,Z), logprob_p, logprob_q, kl_samplewise (N,), kl_spatial (N,H,W)."""
+def normal_stochastic_fwd(p, q, eps_or_z, mode, analytical_kl, Z, N, rows=None):
+    """p (N|1,H,W,2Z), q (N,H,W,2Z)|None. Returns z (N,H,W,Z), logprob_p, logprob_q, kl_samplewise (N,), kl_spatial (N,H,W).
+    rows = (logprob_p row, kl row): (N,) views of the model's [L][N] matrices the kernel writes into directly (no stacking copies)."""
     p_bcast = int(p.shape[0] == 1 and N > 1)
     _, H, W, _ = p.shape
     dev = p.device
     z = torch.empty((N, H, W, Z), dtype=torch.float32, device=dev)
     small = torch.empty((3, N), dtype=torch.float32, device=dev)
+    if rows is not None:
+        small = [rows[0], small[1], rows[1]]
     ks = torch.empty((N, H, W), dtype=torch.float32, device=dev) if q is not None else None
     call('lvae_normal_stochastic_fwd_f32', ptr(p), p_bcast, ptr(q), ptr(eps_or_z), N, H * W, Z, mode, int(bool(analytical_kl)),
          ptr(z), ptr(small[0]), ptr(small[1]) if q is not None else None, ptr(small[2]) if q is not None else None, ptr(ks),

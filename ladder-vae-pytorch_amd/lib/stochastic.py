@@ -25,7 +25,7 @@ class NormalStochasticBlock2d(nn.Module):
         self.conv_out = Conv2dParams(c_vars, c_out, kernel, padding=pad)
 
     def forward(self, p_params, q_params=None, forced_latent=None, use_mode=False, force_constant_output=False,
-                analytical_kl=False, noise=None, n_img=None, need_kl_elementwise=True):
+                analytical_kl=False, noise=None, n_img=None, need_kl_elementwise=True, rows=None):
         """need_kl_elementwise=False (engine-only keyword, used by TopDownLayer which drops that key, models/lvae_layers.py:163-170):
         skip the pass that materialises `kl_elementwise` (lib/stochastic.py:88-91); the per-sample and per-pixel sums do not need it."""
         assert (forced_latent is None) or (not use_mode)
@@ -45,7 +45,8 @@ class NormalStochasticBlock2d(nn.Module):
             mode, src = 1, None
         else:
             mode, src = 0, noise.normal((N, H, W, self.c_vars), dev)
-        outs = ops.NormalStochFn.apply(p_params, q_params, src, mode, bool(analytical_kl), self.c_vars, N)
+        # rows: engine-only keyword — (N,) views the kernel writes log p(z) and the KL into (rows of the model's [L][N] matrices)
+        outs = ops.NormalStochFn.apply(p_params, q_params, src, mode, bool(analytical_kl), self.c_vars, N, rows)
         z = outs[0]
         if force_constant_output:
             # lib/stochastic.py:71-73 — prior experiments only (no gradient flows here)

@@ -6,6 +6,8 @@ convention: tensors are returned as permuted views of the engine's NHWC buffers,
 attributes (`n_layers`, `img_shape`, `likelihood`, `global_step`), exceptions, and state_dict key scheme.
 
 Differences by design (not by omission):
+  * `logp` (data['logprob_p'] of topdown_pass) is computed by one kernel from the per-layer rows and carries no autograd graph
+    (the reference never differentiates it: it is a logged metric, experiment/experiment_manager.py does not read it);
   * every arithmetic op is a hand-written gfx950 kernel from liblvae_hip.so; the model refuses to run on CPU;
   * parameters live in one flat arena (arena.py); their gradients are accumulated in place by the wgrad kernels;
   * noise comes from `self.noise` (noise.PhiloxNoise on device; noise.TapeNoise to replay the reference's draws).
@@ -204,8 +206,7 @@ class LadderVAE(nn.Module):
         ll, likelihood_info = self.likelihood(out, x_nhwc, self.noise)
 
         kl_ln = ops.StackFn.apply(*td_data['kl'])  # (L, N)
-        kl_sep, kl_avg_layerwise, scal = ops.KLBookFn.apply(kl_ln, float(self.free_bits))
-        kl_loss, kl = scal.unbind(0)
+        kl_sep, kl_avg_layerwise, kl_loss, kl = ops.KLBookFn.apply(kl_ln, float(self.free_bits))
         self.noise.end()
 
         params = likelihood_info['params']
@@ -235,7 +236,11 @@ class LadderVAE(nn.Module):
         bu_values = []
         for i in range(self.n_layers):
             x = self.bottom_up_layers[i](self._mark(x, 'bottom_up_layers.%d.' % i), self.noise)
-            bu_values.append(x)
+            if i + 1 < self.n_layers:
+                x, x_td = ops.fanout(x, 2)   # consumers: the next bottom-up layer and this level's top-down layer
+            else:
+                x_td = x
+            bu_values.append(x_td)
         return bu_values
 
     def bottomup_pass(self, x):
@@ -263,8 +268,12 @@ class LadderVAE(nn.Module):
         kl_spatial = [None] * self.n_layers
         if forced_latent is None:
             forced_latent = [None] * self.n_layers
-        logprob_p = 0.
         out = None
+        # per-layer, per-sample log p(z) and KL are written by the stochastic kernels straight into the rows of two [L][N] matrices
+        n_rows = bu_values[0].shape[0] if inference_mode else int(n_img_prior)
+        dev = next(self.parameters()).device
+        lp_mat = torch.empty((self.n_layers, n_rows), dtype=torch.float32, device=dev)
+        kl_mat = torch.empty((self.n_layers, n_rows), dtype=torch.float32, device=dev)
         for i in reversed(range(self.n_layers)):
             try:
                 bu_value = bu_values[i]
@@ -280,11 +289,12 @@ class LadderVAE(nn.Module):
             out, _, aux = self.top_down_layers[i](out, skip_connection_input=out, inference_mode=inference_mode,
                                                   bu_value=bu_value, n_img_prior=n_img_prior, use_mode=i in mode_layers,
                                                   force_constant_output=i in constant_layers, forced_latent=fl,
-                                                  noise=self.noise)
+                                                  noise=self.noise, rows=(lp_mat[i], kl_mat[i]))
             z[i] = aux['z']
             kl[i] = aux['kl_samplewise']
             kl_spatial[i] = aux['kl_spatial']
-            logprob_p = logprob_p + aux['logprob_p'].mean()
+        with torch.no_grad():  # models/lvae.py:301: sum over layers of the batch-mean log p(z); a metric (returned without a graph)
+            logprob_p = K.sum_of_row_means(lp_mat).view(())
         out = self._mark(out, 'final_top_down.')
         for mod in self.final_top_down:
             if isinstance(mod, Placeholder):

@@ -7,6 +7,7 @@ takes the model's noise source explicitly.
 import torch
 from torch import nn
 
+from .. import ops
 from ..lib.nn import Conv2dParams, ResidualBlock, ResidualGatedBlock
 from ..lib.stochastic import NormalStochasticBlock2d
 
@@ -152,7 +153,7 @@ class TopDownLayer(nn.Module):
                                                                    res_block_type=res_block_type)
 
     def forward(self, input_=None, skip_connection_input=None, inference_mode=False, bu_value=None, n_img_prior=None,
-                forced_latent=None, use_mode=False, force_constant_output=False, noise=None):
+                forced_latent=None, use_mode=False, force_constant_output=False, noise=None, rows=None):
         inputs_none = input_ is None and skip_connection_input is None
         if self.is_top_layer and not inputs_none:
             raise ValueError("In top layer, inputs should be None")
@@ -162,15 +163,22 @@ class TopDownLayer(nn.Module):
             p_params = self.top_prior_params.permute(0, 2, 3, 1)
             n_img = n_img_prior
         else:
-            p_params = input_
+            # input_ feeds conv_in_p, the merge layer (inference) and — when it is also the skip input, as in LadderVAE — the skip
+            # merger: explicit aliases, so that the three gradients are summed by one kernel (ops.FanoutFn)
+            same_skip = self.stochastic_skip and skip_connection_input is input_
+            al = ops.fanout(input_, 1 + int(inference_mode) + int(same_skip))
+            p_params = al[0]
+            p_merge = al[1] if inference_mode else None
+            if same_skip:
+                skip_connection_input = al[-1]
         if inference_mode:
-            q_params = bu_value if self.is_top_layer else self.merge(bu_value, p_params, noise)
+            q_params = bu_value if self.is_top_layer else self.merge(bu_value, p_merge, noise)
         else:
             q_params = None
         x, data_stoch = self.stochastic(p_params=p_params, q_params=q_params, forced_latent=forced_latent,
                                         use_mode=use_mode, force_constant_output=force_constant_output,
                                         analytical_kl=self.analytical_kl, noise=noise, n_img=n_img,
-                                        need_kl_elementwise=False)
+                                        need_kl_elementwise=False, rows=rows)
         if self.stochastic_skip and not self.is_top_layer:
             x = self.skip_connection_merger(x, skip_connection_input, noise)
         x_pre_residual = x

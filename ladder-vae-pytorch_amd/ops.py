@@ -336,8 +336,8 @@ class NormalStochFn(Function):
     """lib/stochastic.py:45-99 elementwise core. Returns z, logprob_p, logprob_q, kl_samplewise, kl_spatial."""
 
     @staticmethod
-    def forward(ctx, p, q, noise, mode, analytical, Z, N):
-        z, lp, lq, kl, ks = K.normal_stochastic_fwd(p, q, noise, mode, analytical, Z, N)
+    def forward(ctx, p, q, noise, mode, analytical, Z, N, rows=None):
+        z, lp, lq, kl, ks = K.normal_stochastic_fwd(p, q, noise, mode, analytical, Z, N, rows=rows)
         ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernel takes NULL) instead of zero-filled tensors
         ctx.mode, ctx.analytical, ctx.Z = mode, analytical, Z
         ctx.has_q = q is not None
@@ -352,14 +352,14 @@ class NormalStochFn(Function):
         p, q, eps, z = ctx.saved_tensors
         cc = lambda t: None if t is None else _c(t)
         if dz is None and g_lp is None and g_lq is None and g_kl is None and g_ks is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dp, dq = K.normal_stochastic_bwd(p, q, eps, z, cc(dz), cc(g_lp), cc(g_lq), cc(g_kl), cc(g_ks), ctx.mode,
                                          ctx.analytical, ctx.Z)
         if ctx.p_bcast:
             red = torch.empty_like(p)
             K.colsum(dp.view(dp.shape[0], -1), red.view(-1), False)
             dp = red
-        return dp, dq, None, None, None, None, None
+        return dp, dq, None, None, None, None, None, None
 
 
 class KlElementwiseFn(Function):
@@ -483,6 +483,37 @@ def segment_mark(x, tracker, seg):
     return y
 
 
+class FanoutFn(Function):
+    """n aliases of an activation that has n consumers (a top-down layer's input feeds conv_in_p, the merge layer and the skip
+    merger; a bottom-up value feeds the next bottom-up layer and its top-down layer): their gradients are summed by ONE launch of
+    our own kernel instead of autograd's chain of n - 1 tensor adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [_c(g) for g in grads if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            gs = ([K.add3(gs[0], gs[1], gs[2])] + gs[3:]) if len(gs) >= 3 else [K.add(gs[0], gs[1])]
+        return gs[0], None
+
+
+def fanout(x, n):
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    outs = FanoutFn.apply(x, n)
+    parts = getattr(x, '_lvae_bn_parts', None)   # BatchNorm partials travel with the tensor object (lib/nn.py)
+    if parts is not None:
+        for o in outs:
+            o._lvae_bn_parts = parts
+    return outs
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class UpsampleFn(Function):
     @staticmethod
@@ -516,15 +547,23 @@ class KLBookFn(Function):
         ctx.fb = free_bits
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(kl_ln)
-        return K.kl_bookkeeping_fwd(kl_ln, free_bits)
+        kl_sep, kl_avg, scal = K.kl_bookkeeping_fwd(kl_ln, free_bits)
+        kl_loss, kl = scal[0], scal[1]
+        ctx.mark_non_differentiable(kl)   # `kl` (the batch mean of kl_sep) is a metric
+        return kl_sep, kl_avg, kl_loss, kl
 
     @staticmethod
-    def backward(ctx, g_sep, g_avg, g_scal):
+    def backward(ctx, g_sep, g_avg, g_kl_loss, g_kl):
         (kl_ln,) = ctx.saved_tensors
         cc = lambda t: None if t is None else _c(t)
-        if g_sep is None and g_avg is None and g_scal is None:
+        if g_sep is None and g_avg is None and g_kl_loss is None:
             return None, None
-        return K.kl_bookkeeping_bwd(kl_ln, ctx.fb, cc(g_sep), cc(g_avg), cc(g_scal)), None
+        g_scal = None
+        if g_kl_loss is not None:   # [d/d kl_loss, d/d kl = 0] as the kernel expects them, written by our own copy kernel
+            g_scal = torch.empty((2,), dtype=torch.float32, device=kl_ln.device)
+            K.scale_rows_add(cc(g_kl_loss).view(1, 1), None, None, out=g_scal[0:1])
+            K.fill_zero(g_scal[1:2])
+        return K.kl_bookkeeping_bwd(kl_ln, ctx.fb, cc(g_sep), cc(g_avg), g_scal), None
 
 
 class StackFn(Function):
@@ -532,7 +571,12 @@ class StackFn(Function):
 
     @staticmethod
     def forward(ctx, *rows):
-        out = torch.empty((len(rows), rows[0].numel()), dtype=torch.float32, device=rows[0].device)
+        L, N = len(rows), rows[0].numel()
+        base = rows[0].data_ptr()
+        if all(r.is_contiguous() and r.data_ptr() == base + 4 * N * i for i, r in enumerate(rows)):
+            # the stochastic kernels wrote their per-sample sums straight into the rows of one [L][N] matrix (models/lvae.py)
+            return rows[0].new_empty(0).set_(rows[0].untyped_storage(), rows[0].storage_offset(), (L, N), (N, 1))
+        out = torch.empty((L, N), dtype=torch.float32, device=rows[0].device)
         for i, r in enumerate(rows):
             K.scale_rows_add(_c(r).view(1, -1), None, None, out=out[i])
         return out
@@ -551,11 +595,11 @@ class ElboLossFn(Function):
         ctx.beta, ctx.N = beta, ll.numel()
         ctx.kl_dim0 = kl_loss.dim() == 0
         elbo_sep, scal = K.elbo_loss_fwd(ll, kl_sep, kl_loss, beta)
-        ctx.mark_non_differentiable(elbo_sep)
-        return elbo_sep, scal
+        loss, elbo, recons = scal[0], scal[1], scal[2]
+        ctx.mark_non_differentiable(elbo_sep, elbo, recons)   # only d(loss) is propagated; elbo / recons are metrics
+        return elbo_sep, loss, elbo, recons
 
     @staticmethod
-    def backward(ctx, g_sep, g_scal):
-        # only d(loss) is propagated; elbo / recons are metrics
-        d_ll, d_kl = K.elbo_loss_bwd(_c(g_scal)[0:1], ctx.beta, ctx.N)
+    def backward(ctx, g_sep, g_loss, g_elbo, g_recons):
+        d_ll, d_kl = K.elbo_loss_bwd(_c(g_loss).view(1), ctx.beta, ctx.N)
         return d_ll, None, d_kl.view(()) if ctx.kl_dim0 else d_kl, None
