@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 9
+#define LVAE_ABI_VERSION 10
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -356,6 +356,10 @@ int lvae_elbo_loss_bwd_f32(const float* g_loss, float beta, int32_t N, float* d_
 /* Importance-weighted bound — evaluate.py:30,86-87 (the loop is boilr's test_procedure: S forward passes, then
  * logsumexp - log S). elbo [S,N] (sample-major) -> out[n] = log mean_s exp(elbo[s][n]). */
 int lvae_iw_logmeanexp_f32(const float* elbo, int32_t S, int32_t N, float* out, void* stream);
+/* The same bound accumulated one sample at a time (so that a captured top-down + likelihood graph can be replayed S times):
+ * state [3][N] = running max, sum of exp(elbo - max), plain sum. mode 0: initialise; mode 1: fold in elbo [N]; mode 2: iw[n] = max +
+ * log(sumexp) - log S and mean[n] = sum / S. */
+int lvae_iw_online_f32(const float* elbo, float* state, int32_t N, int32_t mode, int32_t S, float* iw, float* mean, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser and norms over the flat parameter arena — torch.optim.Adamax at experiment_manager.py:76-81 and the

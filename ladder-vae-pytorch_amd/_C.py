@@ -42,7 +42,7 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 9  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 10  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -100,6 +100,7 @@ SIGNATURES = {
     'lvae_kl_bookkeeping_bwd_f32': (C.c_int, [_P, _I, _I, _F, _P, _P, _P, _P, _P]),
     'lvae_elbo_loss_fwd_f32': (C.c_int, [_P, _P, _P, _F, _I, _P, _P, _P]),
     'lvae_elbo_loss_bwd_f32': (C.c_int, [_P, _F, _I, _P, _P, _P]),
+    'lvae_iw_online_f32': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P]),
     'lvae_iw_logmeanexp_f32': (C.c_int, [_P, _I, _I, _P, _P]),
     'lvae_adamax_step_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P]),
     'lvae_sumsq_workspace': (_Z, [_L]),

@@ -208,6 +208,28 @@ __global__ __launch_bounds__(256) void iw_logmeanexp_kernel(const float* __restr
   out[n] = mx + (float)log(acc) - logf((float)S);
 }
 
+// The same bound accumulated ONLINE, one sample at a time (state [3][N]: running max, sum of exp(elbo - max), plain sum), so that a
+// captured top-down + likelihood graph can be replayed S times without an S x N buffer or a per-replay output pointer:
+//   mode 0: init state;  mode 1: fold in one sample's elbo [N];  mode 2: iw[n] = max + log(sumexp) - log S, mean[n] = sum / S
+__global__ __launch_bounds__(256) void iw_online_kernel(const float* __restrict__ elbo, float* __restrict__ state, int N, int mode, int S,
+                                                        float* iw, float* mean) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  if (mode == 0) {
+    state[n] = -INFINITY;
+    state[N + n] = 0.f;
+    state[2 * N + n] = 0.f;
+  } else if (mode == 1) {
+    const float e = elbo[n], m0 = state[n], m1 = fmaxf(m0, e);
+    state[N + n] = state[N + n] * expf(m0 - m1) + expf(e - m1);   // exp(-inf) = 0 on the first sample
+    state[n] = m1;
+    state[2 * N + n] += e;
+  } else {
+    iw[n] = state[n] + logf(state[N + n]) - logf((float)S);
+    mean[n] = state[2 * N + n] / (float)S;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Adamax over the flat arena (torch.optim.Adamax semantics) and L2 norm
 // ---------------------------------------------------------------------------------------------------------
@@ -422,6 +444,15 @@ extern "C" int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream
   LVAE_REQUIRE(counter != nullptr, LVAE_EINVAL, "lvae_counter_advance: null counter");
   hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, by);
   LVAE_LAUNCH_CHECK("counter_advance");
+  return 0;
+}
+
+extern "C" int lvae_iw_online_f32(const float* elbo, float* state, int32_t N, int32_t mode, int32_t S, float* iw, float* mean, void* stream) {
+  LVAE_REQUIRE(state && N > 0 && mode >= 0 && mode <= 2, LVAE_EINVAL, "lvae_iw_online_f32: bad args");
+  LVAE_REQUIRE(mode != 1 || elbo, LVAE_EINVAL, "lvae_iw_online_f32: elbo missing");
+  LVAE_REQUIRE(mode != 2 || (iw && mean && S > 0), LVAE_EINVAL, "lvae_iw_online_f32: outputs missing");
+  hipLaunchKernelGGL(iw_online_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, elbo, state, N, mode, S, iw, mean);
+  LVAE_LAUNCH_CHECK("iw_online");
   return 0;
 }
 

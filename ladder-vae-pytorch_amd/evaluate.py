@@ -18,8 +18,14 @@ from . import ops
 
 
 @torch.no_grad()
-def iw_log_likelihood(model, x, n_samples):
-    """Returns (iw_bound (N,), elbo_mean (N,)): the S-sample importance-weighted bound and the mean single-sample ELBO."""
+def iw_log_likelihood(model, x, n_samples, use_graph=None):
+    """Returns (iw_bound (N,), elbo_mean (N,)): the S-sample importance-weighted bound and the mean single-sample ELBO.
+
+    The bottom-up pass runs once; one sample = top-down pass + likelihood + KL bookkeeping + an ONLINE update of the per-image
+    (max, sum exp, sum) state. With on-device Philox noise that sample is captured once as a hipGraph and replayed (the RNG
+    step counter is advanced inside the graph): ~1.5 k launches x S without host work, which is what makes S = 1000 practical.
+    use_graph=None: graph when the noise source is PhiloxNoise and S >= 8; a replayed noise tape (parity tests) runs eagerly."""
+    from .noise import PhiloxNoise
     was_training = model.training
     model.eval()
     try:
@@ -31,21 +37,44 @@ def iw_log_likelihood(model, x, n_samples):
         x_pad = K.pad_crop(x, True, model.get_padded_size(x.size()), False)
         x_nhwc = x_pad if img_size == tuple(x_pad.shape[1:3]) else K.pad_crop(x, True, img_size, False)
         bu_values = model._bottomup(x_pad)           # once: sample independent in eval mode
-        N = x.shape[0]
-        elbo = torch.empty((n_samples, N), dtype=torch.float32, device=x.device)
-        for s in range(n_samples):
+        model.noise.end()
+        N, dev = x.shape[0], x.device
+        state = torch.empty((3, N), dtype=torch.float32, device=dev)
+        zero = torch.zeros(1, device=dev)
+        K.iw_online(state, 0)
+
+        def one_sample():
+            model.noise.begin(dev)                   # every sample: same call sites, next RNG step
             out, td = model._topdown(bu_values)
             if tuple(out.shape[1:3]) != img_size:
                 out = ops.CropFn.apply(out, img_size)
             ll, _ = model.likelihood(out, x_nhwc, model.noise)
             kl_ln = ops.StackFn.apply(*td['kl'])
             kl_sep, _, _ = K.kl_bookkeeping_fwd(kl_ln, float(model.free_bits))
-            zero = torch.zeros(1, device=x.device)
             elbo_sep, _ = K.elbo_loss_fwd(ll, kl_sep, zero, 1.0)
-            K.scale_rows_add(elbo_sep.view(1, -1), None, None, out=elbo[s])
-        model.noise.end()
-        iw = K.iw_logmeanexp(elbo)
-        return iw, elbo.mean(0)
+            K.iw_online(state, 1, elbo=elbo_sep)
+            model.noise.end()
+
+        if use_graph is None:
+            use_graph = isinstance(model.noise, PhiloxNoise) and n_samples >= 8
+        done = 0
+        if use_graph:
+            for _ in range(2):                        # eager: allocator warm-up (these count as samples)
+                one_sample()
+            done = 2
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                one_sample()
+            for _ in range(done, n_samples):
+                graph.replay()
+        else:
+            for _ in range(n_samples):
+                one_sample()
+        iw = torch.empty((N,), dtype=torch.float32, device=dev)
+        mean = torch.empty((N,), dtype=torch.float32, device=dev)
+        K.iw_online(state, 2, S=n_samples, iw=iw, mean=mean)
+        return iw, mean
     finally:
         model.train(was_training)
 

@@ -738,6 +738,11 @@ def iw_logmeanexp(elbo_sn):
     return out
 
 
+def iw_online(state, mode, elbo=None, S=0, iw=None, mean=None):
+    """state (3, N). mode 0 init / 1 accumulate elbo (N,) / 2 finalize into iw, mean (N,)."""
+    call('lvae_iw_online_f32', ptr(elbo), ptr(state), state.shape[1], int(mode), int(S), ptr(iw), ptr(mean), stream_ptr())
+
+
 def adamax_step(p, g, exp_avg, exp_inf, mask, lr, beta1, beta2, eps, weight_decay, gscale, step_count):
     call('lvae_adamax_step_f32', ptr(p), ptr(g), ptr(exp_avg), ptr(exp_inf), ptr(mask), p.numel(), lr, beta1, beta2, eps,
          weight_decay, ptr(gscale), step_count.data_ptr(), stream_ptr())

@@ -323,3 +323,22 @@ def test_data_dependent_init_is_a_fixed_point_after_one_pass():
     out = model(x)                           # the product path still runs after the in-place updates
     assert torch.isfinite(out['ll']).all()
 
+
+
+def test_iw_log_likelihood_graph_replay_matches_eager_loop():
+    """evaluate.py:30,56-66 (S-sample IW bound): the captured top-down + likelihood sample replayed S times must give the bound the
+    eager loop gives with the same Philox stream; S = 200 exercises the online log-sum-exp state."""
+    from lvae_amd.evaluate import iw_log_likelihood
+    from lvae_amd.noise import PhiloxNoise
+    g = load_golden('tiny_cifar')
+    m, _ = build(g, training=False)
+    x = g.t('x').cuda()
+    res = []
+    for use_graph in (False, True):
+        m.noise = PhiloxNoise(seed=11)
+        res.append(iw_log_likelihood(m, x, 200, use_graph=use_graph))
+    (iw0, e0), (iw1, e1) = res
+    torch.testing.assert_close(iw1, iw0, rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(e1, e0, rtol=1e-6, atol=1e-3)
+    assert float((iw0 - e0).min()) >= -1e-3            # Jensen
+    assert float((iw0 - e0).max()) > 0.1               # ... and the samples really differ from replay to replay
