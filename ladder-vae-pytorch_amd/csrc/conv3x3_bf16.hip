@@ -265,6 +265,186 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient with bf16 operands:  dW[tap][ci][co] += sum_pixels T(x)[pixel + tap][ci] * dy[pixel][co],  db[co] += sum dy
+// (T = the fused BatchNorm-apply + activation of the forward). The reduction runs over PIXELS, so both MFMA operands need 8
+// consecutive pixels of one channel per lane while the tensors are NHWC: the x patch and the dy tile are staged as [pixel][channel]
+// bf16 images exactly like the forward kernel's, and the fragments are read with ds_read_b64_tr_b16 (a 4-pixel x 16-channel block
+// per 16 lanes, delivered channel-major: the hardware transpose; semantics probed on the device with tools/tr_probe.hip). A tap
+// shift only changes which pixel rows are addressed, so there is no alignment problem.
+// Persistent: one 512-thread workgroup per CU loops over 128- or 64-pixel tiles; wave = (ci half, co half, tap group {0-4 | 5-8}) keeps
+// its <= 5 accumulator tiles (32 ci x 32 co each) in registers across all tiles; the raw x / dy of the next tile are prefetched
+// into registers during the MFMAs. Per-workgroup partial slabs [workgroup][tap][ci][co] + [workgroup][co], fixed-order reduce.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct BfWgArgs {
+  lvae_conv_desc d;
+  const float* dy;
+  float* slab_w;   // [nwg][9][Cin][Cout]
+  float* slab_b;   // [nwg][Cout] or null
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntiles, Cin, bm;
+  uint32_t m_thw, m_tw, m_per_img, m_halo_w, m_tiles_h;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {
+  // two transposed 4 x 16 blocks -> the 8 consecutive k (pixels) of this lane's channel
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int MI>  // tile = 64 * MI pixels
+__global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
+  constexpr int BM = 64 * MI, LDK = BF_LDK, KS = BM / 16;   // k-steps of 16 pixels per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* Xs = reinterpret_cast<__bf16*>(smem_raw);          // [halo_px][LDK]
+  __bf16* Ds = Xs + (size_t)a.halo_px * LDK;                  // [BM][LDK]
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cih = wave & 1, coh = (wave >> 1) & 1, tg = wave >> 2;   // ci half, co half, tap group
+  const int tap0 = tg * 5, ntap = tg == 0 ? 5 : 4;
+  const int li = lane & 31, lh = lane >> 5, G = lane >> 4, i16 = lane & 15;
+  const int Cin = a.Cin, co0 = blockIdx.y * 64;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- transposed-read row of this lane for each (k-step, half-read): tile pixel 16 s + 8 (G >> 1) + 4 rd + (i16 >> 2)
+  int xrow[KS][2];   // halo pixel index of tap (0, 0)
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int p = 16 * s + 8 * (G >> 1) + 4 * rd + (i16 >> 2);
+      const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
+      const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
+      xrow[s][rd] = (img * a.halo_h + ty) * a.halo_w + tx;
+    }
+  const int chx = cih * 32 + 16 * (G & 1) + 4 * (i16 & 3);   // channel offset of this lane's 8-byte piece in an x row
+  const int chd = coh * 32 + 16 * (G & 1) + 4 * (i16 & 3);   // ... in a dy row
+  const int drow0 = 8 * (G >> 1) + (i16 >> 2);
+
+  // ---- staging maps: thread -> (pixel, 4 channels); raw operands of the next tile live in registers during the MFMAs
+  constexpr int XV = 7;        // float4 of the x patch per thread (halo_px <= 224 checked on the host)
+  constexpr int DV = BM / 32;  // float4 of the dy tile per thread
+  const int c4 = (t & 15) * 4, px0 = t >> 4;
+  const bool cx_ok = c4 < Cin, cd_ok = co0 + c4 < d.Cout;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+  if (d.in_scale && cx_ok) {
+    sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
+    sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
+  }
+  const int per_img = a.halo_h * a.halo_w;
+  f32x4 xr[XV], dr[DV];
+  unsigned xok = 0, dok = 0;
+  auto prefetch = [&](int tile) {
+    const int ig = fastdiv(tile, a.m_tiles_h), th_idx = tile - ig * a.tiles_h;
+    const int n0 = ig * a.NI, oh0 = th_idx * a.TH;
+    xok = 0;
+#pragma unroll
+    for (int u = 0; u < XV; ++u) {
+      const int px = px0 + 32 * u;
+      const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+      const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+      const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+      const bool ok = (px < a.halo_px) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & cx_ok;
+      const size_t off = ok ? ((size_t)(n * d.H + ih) * d.W + iw) * Cin + c4 : 0;
+      xr[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      xok |= ok ? (1u << u) : 0u;
+    }
+    dok = 0;
+    const int tile_px = a.NI * a.TH * a.TW;
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+      const int p = px0 + 32 * u;
+      const int img = fastdiv(p, a.m_thw);
+      const bool ok = (p < tile_px) & (n0 + img < d.N) & cd_ok;
+      const size_t off = ok ? ((size_t)(n0 * d.H + oh0) * d.W + p) * d.Cout + co0 + c4 : 0;
+      dr[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
+      dok |= ok ? (1u << u) : 0u;
+    }
+  };
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f32x4 bsum = zero4;
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    // ---- registers -> LDS images (transform + round to bf16); rows that do not exist are zero
+#pragma unroll
+    for (int u = 0; u < XV; ++u) {
+      const int px = px0 + 32 * u;
+      if (px < a.halo_px) {
+        f32x4 w = zero4;
+        if ((xok >> u) & 1u) {
+          w = xr[u];
+          if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
+        }
+        bf16x4 pl[1];
+        split4<1>(w, pl);
+        *reinterpret_cast<bf16x4*>(Xs + px * LDK + c4) = pl[0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+      const int p = px0 + 32 * u;
+      const f32x4 w = ((dok >> u) & 1u) ? dr[u] : zero4;
+      bsum += w;
+      bf16x4 pl[1];
+      split4<1>(w, pl);
+      *reinterpret_cast<bf16x4*>(Ds + p * LDK + c4) = pl[0];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 bfr = tr_frag(Ds + (16 * s + drow0) * LDK + chd, Ds + (16 * s + drow0 + 4) * LDK + chd);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < ntap) {
+          const int tap = tap0 + j, kh = tap / 3, kw = tap - kh * 3;
+          const int off = kh * a.halo_w + kw;
+          const bf16x8 afr = tr_frag(Xs + (xrow[s][0] + off) * LDK + chx, Xs + (xrow[s][1] + off) * LDK + chx);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // the images are read: the next tile overwrites them
+  }
+
+  // ---- partial slabs straight from the accumulators (row = ci, 32 consecutive co per lane half)
+  float* sw = a.slab_w + (size_t)blockIdx.x * 9 * Cin * d.Cout;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j < ntap) {
+      const int tap = tap0 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = co0 + coh * 32 + li;
+        if (ci < Cin && co < d.Cout) sw[((size_t)tap * Cin + ci) * d.Cout + co] = acc[j][r];
+      }
+    }
+  }
+  if (a.slab_b) {
+    float* red = reinterpret_cast<float*>(smem_raw);   // [32 pixel groups][64]
+    *reinterpret_cast<f32x4*>(red + px0 * 64 + c4) = bsum;
+    __syncthreads();
+    if (t < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) v += red[g * 64 + t];
+      if (co0 + t < d.Cout) a.slab_b[(size_t)blockIdx.x * d.Cout + co0 + t] = v;
+    }
+  }
+}
+
 static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- weight pre-split: piece `plane` of w[tap][k][n] (any strides) in MFMA B-fragment order, zero beyond K / N
@@ -450,6 +630,63 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
   a.ntn = (d->Cout + 63) / 64;
   if (a.bm == 128) return split == 1 ? launch_bf<1, 2>(a, s) : launch_bf<3, 2>(a, s);
   return split == 1 ? launch_bf<1, 1>(a, s) : launch_bf<3, 1>(a, s);
+}
+
+// ---- bf16 weight gradient: host side
+static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
+  static const bool off = getenv("LVAE_DISABLE_BF16_WGRAD") != nullptr;  // A/B switch, profiling only
+  if (off || d->precision != LVAE_PREC_BF16) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->gather != LVAE_GATHER_CONV || d->x2 != nullptr) return false;
+  if (d->OH != d->H || d->OW != d->W || d->C1 > 64 || d->C1 % 4 != 0 || d->Cout % 4 != 0) return false;
+  if (!al16b(d->x) || !al16b(d->in_scale) || !al16b(d->in_shift)) return false;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  if (M < 256 * 64 || M * 64 >= ((int64_t)1 << 31)) return false;
+  BfArgs g;
+  int bm = 128;
+  if (!bf_plan_bm(d, 1, 128, g) || g.halo_px > 224 || (g.NI * g.TH * g.TW) % 16 != 0 ||
+      (int64_t)((d->N + g.NI - 1) / g.NI) * g.tiles_h < 256) {   // fewer tiles than CUs: 64-pixel tiles
+    bm = 64;
+    if (!bf_plan_bm(d, 1, 64, g) || g.halo_px > 224 || (g.NI * g.TH * g.TW) % 16 != 0) return false;
+  }
+  if (g.NI * g.TH * g.TW != bm) return false;   // whole 16-pixel k-steps only (image widths 8, 16, 32 ...)
+  a.TH = g.TH; a.TW = g.TW; a.NI = g.NI; a.tiles_h = g.tiles_h; a.halo_w = g.halo_w; a.halo_h = g.halo_h; a.halo_px = g.halo_px;
+  a.m_thw = g.m_thw; a.m_tw = g.m_tw; a.m_per_img = g.m_per_img; a.m_halo_w = g.m_halo_w; a.m_tiles_h = fastdiv_magic(g.tiles_h);
+  a.ntiles = ((d->N + g.NI - 1) / g.NI) * g.tiles_h;
+  a.Cin = d->C1;
+  a.bm = bm;
+  return true;
+}
+
+static int bfwg_nwg(const BfWgArgs& a) { return a.ntiles < 256 ? a.ntiles : 256; }
+
+size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d) {
+  BfWgArgs a;
+  if (!bfwg_plan(d, a)) return 0;
+  return (size_t)bfwg_nwg(a) * ((size_t)9 * d->C1 * d->Cout + d->Cout) * sizeof(float);
+}
+
+void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
+                         int64_t sn, float* dw, float* db, hipStream_t s);
+
+// returns kBfNotEligible when the descriptor does not take this kernel
+int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s) {
+  BfWgArgs a;
+  if (!bfwg_plan(d, a) || !al16b(dy) || !al16b(workspace)) return kBfNotEligible;
+  a.d = *d;
+  a.d.in_fold = nullptr;
+  a.dy = dy;
+  const int nwg = bfwg_nwg(a);
+  a.slab_w = static_cast<float*>(workspace);
+  a.slab_b = db ? a.slab_w + (size_t)nwg * 9 * d->C1 * d->Cout : nullptr;
+  size_t lds = ((size_t)a.halo_px + a.bm) * BF_LDK * 2;
+  if (lds < 32 * 64 * 4) lds = 32 * 64 * 4;
+  const dim3 grid(nwg, (d->Cout + 63) / 64);
+  if (a.bm == 128) hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<2>, grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<1>, grid, dim3(512), lds, s, a);
+  LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16");
+  wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 9, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
+  LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16_reduce");
+  return 0;
 }
 
 }  // namespace lvae

@@ -355,6 +355,8 @@ void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s) {
 }
 
 size_t conv_wgrad_wino_workspace(const lvae_conv_desc* d);
+size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d);
+int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
                             void* const* workspace, int n, hipStream_t s);
 int conv_wgrad_tile_kind(const lvae_conv_desc* d);
@@ -464,6 +466,8 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
+  const size_t bf = conv3x3_wgrad_bf16_workspace(d);   // precision = LVAE_PREC_BF16 descriptors that have a bf16 weight-gradient kernel
+  if (bf) return bf;
   const size_t wino = conv_wgrad_wino_workspace(d);
   if (wino) return wino;
   const size_t direct = conv1x1_wgrad_workspace(d);
@@ -486,6 +490,10 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
   static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  if (!halo_off && conv3x3_wgrad_bf16_workspace(d)) {
+    const int hr = conv3x3_wgrad_bf16_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
   if (!halo_off && conv_wgrad_wino_workspace(d)) {
     const int hr = conv_wgrad_wino_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
@@ -571,8 +579,9 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     ws[i] = wp;
     wp += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
     const bool al = (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
-    const bool wino = !halo_off && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
-    const bool groupable = !halo_off && !wino && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
+    const bool bf16 = !halo_off && conv3x3_wgrad_bf16_workspace(&descs[i]) != 0;   // launched one by one (lvae_conv2d_wgrad_f32 below)
+    const bool wino = !halo_off && !bf16 && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
+    const bool groupable = !halo_off && !wino && !bf16 && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
                            conv1x1_wgrad_workspace(&descs[i]) == 0;
     // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
     static const int64_t wino_group_max = getenv("LVAE_WINO_GROUP_MAX_M") ? atoll(getenv("LVAE_WINO_GROUP_MAX_M")) : 65536;  // tuning switch

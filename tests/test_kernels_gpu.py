@@ -706,3 +706,33 @@ def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape):
     # small layers are not taken (the caller composes gate_bwd + wgrad)
     small = K.conv1x1_gate_bwd_wgrad(nhwc(dout[:4]), nhwc(ab.detach()[:4]), nhwc(x.detach()[:4]), wp, geom, 'elu', dw, db) if H * W * 4 < 16384 else None
     assert small is None
+
+
+@pytest.mark.parametrize('case', [(256, 64, 64, 16, 16), (33, 64, 64, 32, 32), (300, 64, 64, 8, 8), (70, 32, 64, 16, 16), (40, 64, 100, 32, 32)])
+def test_conv3x3_wgrad_bf16_operands(K, case):
+    """Weight / bias gradient with bf16 matrix-core operands (transposed LDS reads, persistent accumulators): against the fp64 sum
+    over operands that were rounded to bf16 beforehand, accumulating into non-zero gradient buffers; fused BN+ELU prologue."""
+    N, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    sc, sh = 1 + 0.1 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / 24
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 1)
+    bf = lambda t: t.bfloat16().double()
+    xin = F.elu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xin64 = bf(xin).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(xin64, w64, None, padding=1).backward(bf(dy))
+    dw0, db0 = torch.randn(Co, Ci, 3, 3, generator=g) * 0.1, torch.randn(Co, generator=g)
+    dw, db = packed_weight(dw0), db0.cuda()
+    K.set_precision('bf16')
+    try:
+        d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
+        assert K._C.load().lvae_conv2d_wgrad_workspace(ctypes.byref(d)) > 0
+        K.conv2d_wgrad(nhwc(x), nhwc(dy), wp, geom, dw, db, in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu')
+    finally:
+        K.set_precision('f32')
+    assert rel(dw.cpu() - dw0, w64.grad.float()) < 3e-4     # bf16 rounding boundaries of the GPU's fast-exp ELU vs the CPU's
+    assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 1e-5    # the bias gradient sums the unrounded dy
