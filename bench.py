@@ -326,9 +326,9 @@ def main():
         K.set_precision('f32')
         gbs = b16 / (ms16 * 1e-3) / 1e9
         line['bf16_shard'] = {
-            'config': 'BASELINE configs[3] per-GPU shard: CIFAR10 15-layer, batch %d, compute_dtype bf16 (3x3 convolutions of the 8x8..32x32 '
-                      'levels on v_mfma_f32_32x32x16_bf16, fp32 storage / accumulate / statistics / KL / likelihood; weight gradients, 1x1 '
-                      'and <=4x4 convolutions still fp32)' % args.batch,
+            'config': 'BASELINE configs[3] per-GPU shard: CIFAR10 15-layer, batch %d, compute_dtype bf16 (forward, dgrad and weight gradient of the 3x3 '
+                      'convolutions of the 8x8..32x32 levels on v_mfma_f32_32x32x16_bf16, fp32 storage / accumulate / statistics / KL / '
+                      'likelihood; 1x1 and <=4x4 convolutions still fp32)' % args.batch,
             'value': args.batch / s16, 'unit': 'images/s', 'ms_per_step': s16 * 1e3, 'steps': n16, 'dtype': 'bf16',
             'neg_elbo': -float(out16['elbo']),
             'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM, 'traffic': None,

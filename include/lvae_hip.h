@@ -16,7 +16,7 @@
  *    kernel (an idempotent hipFuncSetAttribute on first use). Read-only process state: the tuning / A-B switches below, each read
  *    from the environment once on first use; every value selects among kernel variants that pass the same parity tests:
  *      LVAE_DISABLE_WINO, LVAE_DISABLE_WINO_WGRAD, LVAE_DISABLE_HALO, LVAE_DISABLE_W1X1   (fall back to the direct kernels)
- *      LVAE_F32_SPLIT (1: run the large fp32 3x3 layers as six exact bf16-piece products on the bf16 MFMA instead of Winograd-fp32), LVAE_DISABLE_POS, LVAE_DISABLE_GATE_FUSED, LVAE_GATE_FUSED_MIN_M,
+ *      LVAE_F32_SPLIT (1: run the large fp32 3x3 layers as six exact bf16-piece products on the bf16 MFMA instead of Winograd-fp32), LVAE_DISABLE_POS, LVAE_DISABLE_GATE_FUSED, LVAE_DISABLE_BF16_WGRAD, LVAE_BF16_WGRAD_TPW, LVAE_GATE_FUSED_MIN_M,
  *      LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
  *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
  *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the

@@ -310,17 +310,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   const int Cin = a.Cin, co0 = blockIdx.y * 64;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---- transposed-read row of this lane for each (k-step, half-read): tile pixel 16 s + 8 (G >> 1) + 4 rd + (i16 >> 2)
-  int xrow[KS][2];   // halo pixel index of tap (0, 0)
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int p = 16 * s + 8 * (G >> 1) + 4 * rd + (i16 >> 2);
-      const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
-      const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
-      xrow[s][rd] = (img * a.halo_h + ty) * a.halo_w + tx;
-    }
+  // ---- transposed-read row of this lane for (k-step s, half-read rd): tile pixel 16 s + 8 (G >> 1) + 4 rd + (i16 >> 2) -> halo pixel
+  // index of tap (0, 0); recomputed per k-step (two magic divisions) rather than held in 16 registers
+  auto xrow_of = [&](int s, int rd) {
+    const int p = 16 * s + 8 * (G >> 1) + 4 * rd + (i16 >> 2);
+    const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
+    const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
+    return (img * a.halo_h + ty) * a.halo_w + tx;
+  };
   const int chx = cih * 32 + 16 * (G & 1) + 4 * (i16 & 3);   // channel offset of this lane's 8-byte piece in an x row
   const int chd = coh * 32 + 16 * (G & 1) + 4 * (i16 & 3);   // ... in a dy row
   const int drow0 = 8 * (G >> 1) + (i16 >> 2);
@@ -403,15 +400,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
 
-#pragma unroll
+#pragma unroll 2
     for (int s = 0; s < KS; ++s) {
+      const int xr0 = xrow_of(s, 0), xr1 = xrow_of(s, 1);
       const bf16x8 bfr = tr_frag(Ds + (16 * s + drow0) * LDK + chd, Ds + (16 * s + drow0 + 4) * LDK + chd);
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         if (j < ntap) {
           const int tap = tap0 + j, kh = tap / 3, kw = tap - kh * 3;
           const int off = kh * a.halo_w + kw;
-          const bf16x8 afr = tr_frag(Xs + (xrow[s][0] + off) * LDK + chx, Xs + (xrow[s][1] + off) * LDK + chx);
+          const bf16x8 afr = tr_frag(Xs + (xr0 + off) * LDK + chx, Xs + (xr1 + off) * LDK + chx);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
         }
       }
@@ -657,7 +655,15 @@ static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
   return true;
 }
 
-static int bfwg_nwg(const BfWgArgs& a) { return a.ntiles < 256 ? a.ntiles : 256; }
+// workgroups = split-K ranges = partial slabs (147 KB each for 64 -> 64): the slab write + reduce traffic, not the MFMAs, is what this
+// kernel costs; measured on the CIFAR-15 step (bf16 mode): 2 tiles per workgroup 33.3 ms, 4 -> 33.7, 8 -> 36.1
+static int bfwg_nwg(const BfWgArgs& a) {
+  static const int tpw = getenv("LVAE_BF16_WGRAD_TPW") ? atoi(getenv("LVAE_BF16_WGRAD_TPW")) : 2;  // tuning switch
+  int n = (a.ntiles + tpw - 1) / tpw;
+  if (n > 256) n = 256;
+  if (n < 1) n = 1;
+  return n;
+}
 
 size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d) {
   BfWgArgs a;
