@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 10
+#define LVAE_ABI_VERSION 11
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -189,6 +189,11 @@ int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, 
 size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* The same gradient with bf16 matrix-core operands (transposed LDS reads feed v_mfma_f32_32x32x16_bf16; fp32 accumulation, fp32 bias
+ * gradient, fp32 partial slabs): lvae_conv2d_wgrad_f32 on a descriptor with precision = LVAE_PREC_BF16. Shapes without a bf16
+ * kernel (anything but 3x3 / stride 1 / <= 64 input channels / >= 16384 pixels) run in fp32. */
+int lvae_conv2d_wgrad_bf16(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* n independent weight gradients (descs[i], dy[i], dw[i], db[i]; db[i] may be NULL): same results as n calls of
  * lvae_conv2d_wgrad_f32 in index order. The low-resolution levels of the ladder fill 16-64 CUs per gradient and depend on
  * nothing but their own inputs, so launches that share a kernel variant go out together (up to 12 per launch, one grouped

@@ -42,7 +42,7 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 10  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 11  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -65,6 +65,7 @@ SIGNATURES = {
     'lvae_conv1x1_gate_bwd_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _L, _L, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    'lvae_conv2d_wgrad_bf16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_grouped_workspace': (_Z, [C.POINTER(ConvDesc), _I]),
     'lvae_conv2d_wgrad_grouped_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),

@@ -554,6 +554,14 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   return 0;
 }
 
+extern "C" int lvae_conv2d_wgrad_bf16(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  LVAE_REQUIRE(d != nullptr, LVAE_EINVAL, "lvae_conv2d_wgrad_bf16: null descriptor");
+  lvae_conv_desc dd = *d;
+  dd.precision = LVAE_PREC_BF16;
+  return lvae_conv2d_wgrad_f32(&dd, dy, dw, db, workspace, workspace_bytes, stream);
+}
+
 // n independent weight gradients; same result as n calls of lvae_conv2d_wgrad_f32. Launches that share a tile-kernel
 // variant and are float4-aligned go out together (<= 12 per launch), everything else one by one.
 extern "C" size_t lvae_conv2d_wgrad_grouped_workspace(const lvae_conv_desc* descs, int32_t n) {
