@@ -86,7 +86,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
 #pragma unroll
     for (int p = 0; p < SPLIT; ++p) r[p] = *reinterpret_cast<const bf16x8*>(src + p * 1024);
   };
-  if (!(a.debug & 8)) {
+  // SPLIT == 1: a k-step is only MI MFMAs (64-128 cycles), far shorter than an L2 round trip, so a two-step ring stalls on every
+  // step (measured: 20 us per tile, ~10 of them waiting for fragments). The wave's whole B slice — 36 fragments, 144 registers —
+  // is fetched up front instead, while the patch is being staged.
+  bf16x8 ball[SPLIT == 1 ? 36 : 1];
+  if (SPLIT == 1) {
+#pragma unroll
+    for (int st = 0; st < 36; ++st) {
+      bf16x8 tmp[SPLIT];
+      load_b(st, tmp);
+      ball[SPLIT == 1 ? st : 0] = tmp[0];
+    }
+  } else if (!(a.debug & 8)) {
     load_b(0, bq[0]);
     load_b(1, bq[1]);
   }
@@ -174,8 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   for (int step = 0; step < 36; ++step) {
     if (a.debug & 4) break;
     const int cur = step & 1;
-    if (step + 2 < 36 && !(a.debug & 8)) load_b(step + 2, bq[(step + 2) % 3]);
+    if (SPLIT != 1 && step + 2 < 36 && !(a.debug & 8)) load_b(step + 2, bq[(step + 2) % 3]);
     if (step + 1 < 36) load_a(step + 1, af[cur ^ 1]);
+    if (SPLIT == 1) bq[step % 3][0] = ball[SPLIT == 1 ? step : 0];
     const bf16x8 (&bf)[SPLIT] = bq[step % 3];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -810,7 +822,9 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
   static const int dbg = lvae::debug_phase_switch("LVAE_BF16_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
   a.debug = dbg;
   a.ntn = (d->Cout + 63) / 64;
-  static const bool persistent = getenv("LVAE_BF16_PERSISTENT") == nullptr || atoi(getenv("LVAE_BF16_PERSISTENT")) != 0;  // A/B switch
+  // measured (CIFAR-15 step, bf16): the persistent form is SLOWER (33.8 vs 33.1 ms/step) — at 256x16x16 there is one tile per
+  // workgroup anyway and at 32x32 the per-tile latency chain, not the overlap, is what counts; kept behind LVAE_BF16_PERSISTENT=1
+  static const bool persistent = getenv("LVAE_BF16_PERSISTENT") != nullptr && atoi(getenv("LVAE_BF16_PERSISTENT")) != 0;  // A/B switch
   if (split == 1 && persistent && a.halo_px <= 208) {
     const int total_tiles = ((d->N + a.NI - 1) / a.NI) * a.tiles_h * a.ntn;
     const int grid = total_tiles < 512 ? total_tiles : 512;   // two workgroups per CU
