@@ -55,7 +55,10 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
 }
 
 // MI: 32-pixel MFMA row blocks per wave; the workgroup tile is BM = 64 * MI output pixels x 64 output channels, 4 waves 2(M) x 2(N)
-template <int SPLIT, int MI>
+// PRE (SPLIT == 1 only): the wave's whole B slice is fetched up front (144 registers, two workgroups per CU) — for layers whose grid is a
+// single round of workgroups, where the per-tile latency chain is the launch time; larger grids keep the three-deep ring (87 registers,
+// five workgroups per CU hide the fragment latency by occupancy instead).
+template <int SPLIT, int MI, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   constexpr int BM = 64 * MI, LDK = BF_LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -89,13 +92,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   // SPLIT == 1: a k-step is only MI MFMAs (64-128 cycles), far shorter than an L2 round trip, so a two-step ring stalls on every
   // step (measured: 20 us per tile, ~10 of them waiting for fragments). The wave's whole B slice — 36 fragments, 144 registers —
   // is fetched up front instead, while the patch is being staged.
-  bf16x8 ball[SPLIT == 1 ? 36 : 1];
-  if (SPLIT == 1) {
+  bf16x8 ball[PRE ? 36 : 1];
+  if (PRE) {
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       bf16x8 tmp[SPLIT];
       load_b(st, tmp);
-      ball[SPLIT == 1 ? st : 0] = tmp[0];
+      ball[PRE ? st : 0] = tmp[0];
     }
   } else if (!(a.debug & 8)) {
     load_b(0, bq[0]);
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   for (int step = 0; step < 36; ++step) {
     if (a.debug & 4) break;
     const int cur = step & 1;
-    if (SPLIT != 1 && step + 2 < 36 && !(a.debug & 8)) load_b(step + 2, bq[(step + 2) % 3]);
+    if (!PRE && step + 2 < 36 && !(a.debug & 8)) load_b(step + 2, bq[(step + 2) % 3]);
     if (step + 1 < 36) load_a(step + 1, af[cur ^ 1]);
-    if (SPLIT == 1) bq[step % 3][0] = ball[SPLIT == 1 ? step : 0];
+    if (PRE) bq[step % 3][0] = ball[PRE ? step : 0];
     const bf16x8 (&bf)[SPLIT] = bq[step % 3];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -786,9 +789,9 @@ int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split) {
   return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
 }
 
-template <int SPLIT, int MI>
+template <int SPLIT, int MI, bool PRE = false>
 static int launch_bf(BfArgs a, hipStream_t s) {
-  auto kern = conv3x3_bf16_kernel<SPLIT, MI>;
+  auto kern = conv3x3_bf16_kernel<SPLIT, MI, PRE>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -836,8 +839,13 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
     LVAE_LAUNCH_CHECK("conv3x3_bf16p");
     return 0;
   }
-  if (a.bm == 128) return split == 1 ? launch_bf<1, 2>(a, s) : launch_bf<3, 2>(a, s);
-  return split == 1 ? launch_bf<1, 1>(a, s) : launch_bf<3, 1>(a, s);
+  if (split == 1) {
+    const int64_t wgs = (int64_t)((d->N + a.NI - 1) / a.NI) * a.tiles_h * a.ntn;
+    const bool pre = wgs <= 512;  // one round of two workgroups per CU (measured: 16x16 19.9 -> 18.0 us, 8x8 13.8 -> 9.8; 32x32 53 -> 65 with it)
+    if (a.bm == 128) return pre ? launch_bf<1, 2, true>(a, s) : launch_bf<1, 2>(a, s);
+    return pre ? launch_bf<1, 1, true>(a, s) : launch_bf<1, 1>(a, s);
+  }
+  return a.bm == 128 ? launch_bf<3, 2>(a, s) : launch_bf<3, 1>(a, s);
 }
 
 // ---- bf16 weight gradient: host side
