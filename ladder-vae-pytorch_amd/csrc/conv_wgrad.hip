@@ -252,12 +252,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     stride = Cout;
   }
   if (src) {
-    for (int k = q; k < ksplit; k += 16) {
+    // 8 independent loads per round trip, added in slab order (a rolled loop pays one memory latency per slab: 7.7 us for 256 slabs)
+    for (int k0 = q; k0 < ksplit; k0 += 16 * 8) {
       if (V == 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-        for (int j = 0; j < 4; ++j) s[j] += v[j];
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 16 * u;
+          v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k < ksplit ? k : q) * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 16 * u < ksplit)
+            for (int j = 0; j < 4; ++j) s[j] += v[u][j];
       } else {
-        s[0] += src[(size_t)k * stride];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 16 * u;
+          v[u] = src[(size_t)(k < ksplit ? k : q) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 16 * u < ksplit) s[0] += v[u];
       }
     }
   }
@@ -323,7 +340,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(ReduceGroup g
     stride = a.Cout;
   }
   if (src)
-    for (int k = q; k < a.ksplit; k += 16) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+    for (int k0 = q; k0 < a.ksplit; k0 += 16 * 8) {  // 8 independent loads per round trip, added in slab order
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 16 * u;
+        v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k < a.ksplit ? k : q) * stride);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 16 * u < a.ksplit) s += v[u];
+    }
   *reinterpret_cast<f32x4*>(&red[q][e * 4]) = s;
   __syncthreads();
   if (q != 0 || !src) return;
