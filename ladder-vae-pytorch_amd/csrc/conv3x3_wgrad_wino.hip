@@ -55,68 +55,55 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_grouped_kernel(WgWinoG
 #include "conv3x3_wgrad_wino_body.inc"
 }
 
-// dw[tap(a,b)][ci][co] += (G^T (sum_ranges slab) G)[a][b]; fixed summation order (16 range slices in order, ranges in order inside a slice).
-// workgroup = (ci, group of 64 co, QUARTER of that group): threads = 4 float4 columns x 16 positions x 16 range slices. A quarter per
-// workgroup (256 workgroups for 64 -> 64) because 64 workgroups reading 512 KB each were bound by per-CU bandwidth (9.7 us for 33.5 MB).
-__device__ __forceinline__ void wino_reduce_body(const float* __restrict__ slab_w, const float* __restrict__ slab_b, int nranges, int ncog,
-                                                 int Cout, int64_t stap, int64_t sk, int64_t sn, float* dw, float* db, int bx) {
-  __shared__ float red[16][16][16];
-  __shared__ float red_b[16][16];
-  const int quarter = bx & 3, rest = bx >> 2;
-  const int ci = rest / ncog, cog = rest % ncog;
-  const int t = threadIdx.x, q = t & 3, p = (t >> 2) & 15, rs = t >> 6;
+// dw[tap(a,b)][ci][co] += (G^T (sum_ranges slab) G)[a][b]; one 1024-thread workgroup per (ci, group of 64 co): threads =
+// 16 float4 columns x 16 positions x 4 range slices; each range contributes one contiguous 4 KB block; fixed summation order.
+__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
+                                                                       int nranges, int ncog, int Cout, int64_t stap, int64_t sk,
+                                                                       int64_t sn, float* dw, float* db) {
+  __shared__ float red[4][16][64];
+  __shared__ float red_b[16][64];
+  const int ci = blockIdx.x / ncog, cog = blockIdx.x % ncog;
+  const int t = threadIdx.x, q = t & 15, p = (t >> 4) & 15, rs = t >> 8;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const float* src = slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + quarter * 16 + q * 4;
+  const float* src = slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + q * 4;
   const size_t rstride = (size_t)2 * ncog * 32 * 16 * 64;
 #pragma unroll 8
-  for (int r = rs; r < nranges; r += 16) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+  for (int r = rs; r < nranges; r += 4) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
   *reinterpret_cast<f32x4*>(&red[rs][p][q * 4]) = s;
   const bool do_b = db != nullptr && ci == 0;
-  if (do_b && t < 256) {
-    const int co = t & 15, slice = t >> 4;
+  if (do_b) {
+    const int co = t & 63, slice = t >> 6;
     float v = 0.f;
 #pragma unroll 4
-    for (int r = slice; r < nranges; r += 16) v += slab_b[(size_t)(r * ncog + cog) * 64 + quarter * 16 + co];
+    for (int r = slice; r < nranges; r += 16) v += slab_b[(size_t)(r * ncog + cog) * 64 + co];
     red_b[slice][co] = v;
   }
   __syncthreads();
-  const int co0 = cog * 64 + quarter * 16;
-  if (t < 48 && co0 + (t & 15) < Cout) {
-    const int co = t & 15, ga = t >> 4;  // output row a of G^T dU G
+  if (t < 192 && cog * 64 + (t & 63) < Cout) {
+    const int co = t & 63, ga = t >> 6;  // output row a of G^T dU G
     float u[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][i * 4 + j][co];
-        u[i][j] = v;
-      }
+      for (int j = 0; j < 4; ++j) u[i][j] = (red[0][i * 4 + j][co] + red[1][i * 4 + j][co]) + (red[2][i * 4 + j][co] + red[3][i * 4 + j][co]);
     // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
     float ra[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       ra[j] = ga == 0 ? u[0][j] + 0.5f * (u[1][j] + u[2][j]) : (ga == 1 ? 0.5f * (u[1][j] - u[2][j]) : 0.5f * (u[1][j] + u[2][j]) + u[3][j]);
     const float g0 = ra[0] + 0.5f * (ra[1] + ra[2]), g1 = 0.5f * (ra[1] - ra[2]), g2 = 0.5f * (ra[1] + ra[2]) + ra[3];
-    float* o = dw + (int64_t)ci * sk + (int64_t)(co0 + co) * sn + (int64_t)(ga * 3) * stap;
+    float* o = dw + (int64_t)ci * sk + (int64_t)(cog * 64 + co) * sn + (int64_t)(ga * 3) * stap;
     o[0] += g0;
     o[stap] += g1;
     o[2 * stap] += g2;
   }
-  if (do_b && t >= 64 && t < 80 && co0 + t - 64 < Cout) {
-    const int co = t - 64;
+  if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < Cout) {
+    const int co = t - 256;
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) v += red_b[k][co];
-    db[co0 + co] += v;
+    db[cog * 64 + co] += v;
   }
-}
-
-__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
-                                                                       int nranges, int ncog, int Cout, int64_t stap, int64_t sk,
-                                                                       int64_t sn, float* dw, float* db) {
-  wino_reduce_body(slab_w, slab_b, nranges, ncog, Cout, stap, sk, sn, dw, db, blockIdx.x);
 }
 
 struct WinoReduceArgs {
@@ -133,8 +120,51 @@ struct WinoReduceGroup {
 
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(WinoReduceGroup g) {
   const WinoReduceArgs& a = g.p[blockIdx.y];
-  if ((int)blockIdx.x >= 256 * a.ncog) return;  // uniform per workgroup, before any barrier
-  wino_reduce_body(a.slab_w, a.slab_b, a.nranges, a.ncog, a.Cout, a.stap, a.sk, a.sn, a.dw, a.db, blockIdx.x);
+  if ((int)blockIdx.x >= 64 * a.ncog) return;
+  __shared__ float red[4][16][64];
+  __shared__ float red_b[16][64];
+  const int ncog = a.ncog, nranges = a.nranges;
+  const int ci = blockIdx.x / ncog, cog = blockIdx.x % ncog;
+  const int t = threadIdx.x, q = t & 15, p = (t >> 4) & 15, rs = t >> 8;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* src = a.slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + q * 4;
+  const size_t rstride = (size_t)2 * ncog * 32 * 16 * 64;
+#pragma unroll 8
+  for (int r = rs; r < nranges; r += 4) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+  *reinterpret_cast<f32x4*>(&red[rs][p][q * 4]) = s;
+  const bool do_b = a.db != nullptr && ci == 0;
+  if (do_b) {
+    const int co = t & 63, slice = t >> 6;
+    float v = 0.f;
+#pragma unroll 4
+    for (int r = slice; r < nranges; r += 16) v += a.slab_b[(size_t)(r * ncog + cog) * 64 + co];
+    red_b[slice][co] = v;
+  }
+  __syncthreads();
+  if (t < 192 && cog * 64 + (t & 63) < a.Cout) {
+    const int co = t & 63, ga = t >> 6;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[i][j] = (red[0][i * 4 + j][co] + red[1][i * 4 + j][co]) + (red[2][i * 4 + j][co] + red[3][i * 4 + j][co]);
+    float ra[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      ra[j] = ga == 0 ? u[0][j] + 0.5f * (u[1][j] + u[2][j]) : (ga == 1 ? 0.5f * (u[1][j] - u[2][j]) : 0.5f * (u[1][j] + u[2][j]) + u[3][j]);
+    const float g0 = ra[0] + 0.5f * (ra[1] + ra[2]), g1 = 0.5f * (ra[1] - ra[2]), g2 = 0.5f * (ra[1] + ra[2]) + ra[3];
+    float* o = a.dw + (int64_t)ci * a.sk + (int64_t)(cog * 64 + co) * a.sn + (int64_t)(ga * 3) * a.stap;
+    o[0] += g0;
+    o[a.stap] += g1;
+    o[2 * a.stap] += g2;
+  }
+  if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < a.Cout) {
+    const int co = t - 256;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red_b[k][co];
+    a.db[cog * 64 + co] += v;
+  }
 }
 
 static bool al16g(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -206,7 +236,7 @@ int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, flo
   else if (d->W == 16) rc = launch_wg_wino<8>(a, s);
   else rc = launch_wg_wino<16>(a, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(256 * a.ncog), dim3(1024), 0, s, a.slab_w, a.slab_b, a.nranges,
+  hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(64 * a.ncog), dim3(1024), 0, s, a.slab_w, a.slab_b, a.nranges,
                      a.ncog, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
   LVAE_LAUNCH_CHECK("conv_wgrad_wino_reduce");
   return 0;
@@ -255,7 +285,7 @@ int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const*
   else if (W == 16) hipLaunchKernelGGL(conv_wgrad_wino_grouped_kernel<8>, dim3(max_wgs, n), dim3(512), lds, s, g);
   else hipLaunchKernelGGL(conv_wgrad_wino_grouped_kernel<16>, dim3(max_wgs, n), dim3(512), lds, s, g);
   LVAE_LAUNCH_CHECK("conv_wgrad_wino_grouped");
-  hipLaunchKernelGGL(conv_wgrad_wino_reduce_grouped_kernel, dim3(256 * max_ncog, n), dim3(1024), 0, s, rg);
+  hipLaunchKernelGGL(conv_wgrad_wino_reduce_grouped_kernel, dim3(64 * max_ncog, n), dim3(1024), 0, s, rg);
   LVAE_LAUNCH_CHECK("conv_wgrad_wino_reduce_grouped");
   return 0;
 }
