@@ -98,11 +98,24 @@ class TrainStep:
         fused = self.allreduce is None or not self.allreduce.active or self.overlap
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures
-        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
-            self.static_out = self._fwd_bwd(self.static_x)
-            if fused:
-                self.opt.step()
+        try:
+            # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures
+            with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
+                self.static_out = self._fwd_bwd(self.static_x)
+                if fused:
+                    self.opt.step()
+        except Exception as e:  # noqa: BLE001
+            if not (self.overlap and self.allreduce is not None and self.allreduce.active):
+                raise
+            # a collective that refuses to be captured: keep the exchange outside the graphs (fwd+bwd graph | eager all-reduce |
+            # Adamax graph) instead of failing the run
+            print('[lvae] capturing the gradient exchange failed (%s: %s); falling back to LVAE_DDP_MODE=split' %
+                  (type(e).__name__, str(e).splitlines()[0] if str(e) else ''), file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            self.overlap = False
+            self.model.grad_tracker = None
+            self.graph_a = self.graph_b = None
+            return self._capture(x)
         if not fused:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
