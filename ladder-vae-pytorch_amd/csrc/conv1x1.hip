@@ -50,6 +50,20 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
   constexpr int BPT = NT * K4 / 256;  // float4 of B per thread (both layouts hold KT*NT floats)
   f32x4 av[APT], bv[BPT];
   const bool gate_bwd = a.gb_dout != nullptr;
+  // gate forward: the residual rows this thread adds in the epilogue, fetched NOW (the epilogue would otherwise pay a second HBM
+  // round trip at the end of every workgroup's dependent chain); same (row, channel) map as the epilogue loop
+  constexpr int RPT = NT >= 128 ? BM * (NT / 8) / 256 : 1;  // float4 of the residual per thread (C = NT / 2 channels)
+  f32x4 resv[RPT];
+  const bool res_pre = a.gate_out != nullptr && a.gate_res != nullptr && NT >= 128 && N == NT;
+  if (res_pre) {
+    const int c4n = N >> 3;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int idx = t + 256 * u, r = idx / c4n, c = (idx - r * c4n) * 4;
+      const int m = m0 + r;
+      resv[u] = *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)(m < a.M ? m : 0) * (N >> 1) + c);
+    }
+  }
   if (!gate_bwd) {
 #pragma unroll
     for (int u = 0; u < APT; ++u) {
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
     const bool stats = d.stats_out != nullptr && (256 % c4n) == 0;
     f32x4 st1 = zero4, st2 = zero4, piv = zero4;
     if (stats) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + (t % c4n) * 4);
-    for (int idx = t; idx < BM * c4n; idx += 256) {
+    int it = 0;
+    for (int idx = t; idx < BM * c4n; idx += 256, ++it) {
       const int r = idx / c4n, c = (idx - r * c4n) * 4;
       const int m = m0 + r;
       if (m >= a.M) continue;
@@ -201,7 +216,15 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       f32x4 o = act_fwd4(va, a.gate_act);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] *= sigmoidf_(vb[j]);
-      if (a.gate_res) o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
+      if (res_pre) {
+        f32x4 rv = resv[0];
+#pragma unroll
+        for (int u = 1; u < RPT; ++u)
+          if (it == u) rv = resv[u];
+        o += rv;
+      } else if (a.gate_res) {
+        o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
+      }
       *reinterpret_cast<f32x4*>(a.gate_out + (size_t)m * C + c) = o;
       const f32x4 dl = o - piv;
       st1 += dl;
