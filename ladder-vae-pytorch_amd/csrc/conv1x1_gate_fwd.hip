@@ -1,0 +1,264 @@
+// GateLayer2d forward of the 64-channel residual blocks (lib/nn.py:118-126 and the residual add of lib/nn.py:99) as a persistent kernel:
+//   ab = x . W + bias            x [M][64], W [64][128]; ab written to d->y when the backward needs it
+//   out[m][c] = act(ab[m][c]) * sigmoid(ab[m][64 + c]) + res[m][c]
+// and, when d->stats_out is set, the BatchNorm partials of `out` (the next residual block's first BatchNorm), one row per workgroup.
+//
+// The layer is bound by its 85 MB of HBM traffic at 256x16x16 (x and res in, ab and out out; 7 us of fp32 MFMA). conv1x1_kernel ran it as
+// 1024 independent 64-pixel workgroups (stage x and W in LDS, MFMA, stage the result in LDS, epilogue), about 1.3 rounds of what the chip
+// holds at once, each round paying the whole dependent chain: 29 us. Here
+//   * at most 512 workgroups (two per CU), each walking over tiles blockIdx.x, blockIdx.x + gridDim.x, ...;
+//   * W lives in registers for the life of the workgroup (64 VGPRs per lane: the B operand of every v_mfma_f32_32x32x2_f32 this wave
+//     issues), so the only LDS traffic is the x tile, double-buffered: tile i+1 is fetched while tile i is in the MFMAs and the epilogue;
+//   * the epilogue works on the accumulators as they stand: one accumulator register across a wave is two 128-byte row segments, which
+//     is a full-rate store shape, and the a- and b-halves of a channel sit in the same lane (wave wn owns columns wn*32 + lane and
+//     64 + wn*32 + lane), so ab, the gate, the residual add and the statistics need no LDS round trip; the residual rows are requested
+//     before the MFMAs of their tile.
+#include <stdlib.h>
+
+#include "lvae_common.h"
+
+namespace lvae {
+
+struct GateFwdArgs {
+  const float* x;     // [M][64]
+  const float* w;     // element (k, n) at w[k * w_sk + n * w_sn]
+  int64_t w_sk, w_sn;
+  const float* bias;  // [128] or null
+  const float* res;   // [M][64] or null
+  float* y;           // [M][128] or null
+  float* out;         // [M][64]
+  float* stats_out;   // [gridDim.x + 1][2][64] or null (last row: the pivot)
+  const float* stats_pivot;
+  int M, tiles, act;
+};
+
+constexpr int GF_BM = 64, GF_LDA = 68;
+
+constexpr int GF_LDO = 40;  // staging row stride (floats): 4 rows = 160 = 32 mod 64 banks, so the two lane halves of a write miss each other
+
+// WT: the three outputs leave as 16-byte write-through stores (store_wt4), transposed from the accumulator layout through a 5 KB LDS
+// strip that belongs to the wave alone (no workgroup barrier: a wave's LDS instructions execute in order); the residual rows are
+// then fetched as float4 in the store layout. !WT: one dword per lane straight from the accumulators, plain stores.
+template <bool WT>
+__global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][GF_BM * GF_LDA];
+  __shared__ __attribute__((aligned(16))) float Os[WT ? 4 : 1][WT ? 32 * GF_LDO : 4];
+  __shared__ __attribute__((aligned(16))) float red[2][2][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ch = wn * 32 + li;  // this lane's channel: column ch of the a half, 64 + ch of the b half
+  const int M = a.M;
+
+  // x tile: thread -> rows (t + 256 u) / 16, four channels; rows past M read row 0 and are masked in the epilogue
+  f32x4 av[4];
+  auto load_a = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
+      const int m = tile * GF_BM + r;
+      av[u] = *reinterpret_cast<const f32x4*>(a.x + (size_t)(m < M ? m : 0) * 64 + k);
+    }
+  };
+  auto store_a = [&](float* dst) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
+      *reinterpret_cast<f32x4*>(dst + r * GF_LDA + k) = av[u];
+    }
+  };
+
+  int tile = blockIdx.x;
+  load_a(tile);
+  // B operands: k-step s = 4 g + j of group g multiplies A[.][8 g + 4 lh + j] (the four floats of this lane's ds_read_b128)
+  float breg[2][32];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t ko = (int64_t)(8 * g + 4 * lh + j) * a.w_sk;
+      breg[0][4 * g + j] = a.w[ko + (int64_t)ch * a.w_sn];
+      breg[1][4 * g + j] = a.w[ko + (int64_t)(64 + ch) * a.w_sn];
+    }
+  const float bias_a = a.bias ? a.bias[ch] : 0.f, bias_b = a.bias ? a.bias[64 + ch] : 0.f;
+  const float piv = a.stats_out ? a.stats_pivot[ch] : 0.f;
+  float st1 = 0.f, st2 = 0.f;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sv1 = zero4, sv2 = zero4, piv4 = zero4;   // WT: statistics in the store layout (four channels per lane)
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;  // WT store layout: rows rr + 8 k of the wave's 32, channels wn*32 + c4 .. + 3
+  if (WT && a.stats_out) piv4 = *reinterpret_cast<const f32x4*>(a.stats_pivot + wn * 32 + c4);
+  float* os = Os[WT ? wave : 0];
+  store_a(As[0]);
+  __syncthreads();
+
+  int cur = 0;
+  for (; tile < a.tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < a.tiles;
+    if (has_next) load_a(next);
+    const int m0 = tile * GF_BM + wm * 32 + 4 * lh;
+    float rv[WT ? 1 : 16];
+    f32x4 rv4[WT ? 4 : 1];
+    const int mw = tile * GF_BM + wm * 32 + rr;  // WT: first of this lane's four rows
+    if (a.res) {
+      if (WT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = mw + 8 * k;
+          rv4[k] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(m < M ? m : 0) * 64 + wn * 32 + c4);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (r & 3) + 8 * (r >> 2);
+          rv[r] = a.res[(size_t)(m < M ? m : 0) * 64 + ch];
+        }
+      }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const float* arow = As[cur] + (wm * 32 + li) * GF_LDA + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[0][4 * g + j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[1][4 * g + j], acc1, 0, 0, 0);
+      }
+    }
+    if (WT) {
+      // accumulator layout -> strip -> (row, four channels) per lane; three passes over the same strip: a half, b half, gate output
+      const int wrow = 4 * lh;  // + (r & 3) + 8 (r >> 2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] += bias_a;
+        acc1[r] += bias_b;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        if (pass < 2 && a.y == nullptr) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = pass == 0 ? acc0[r] : (pass == 1 ? acc1[r] : act_fwd(acc0[r], a.act) * sigmoidf_(acc1[r]));
+          os[(wrow + (r & 3) + 8 * (r >> 2)) * GF_LDO + li] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(os + (rr + 8 * k) * GF_LDO + c4);
+          const int m = mw + 8 * k;
+          if (pass == 2) {
+            if (a.res) v += rv4[k];
+            if (m < M) {
+              store_wt4(a.out + (size_t)m * 64 + wn * 32 + c4, v);
+              const f32x4 dl = v - piv4;
+              sv1 += dl;
+              sv2 += dl * dl;
+            }
+          } else if (m < M) {
+            store_wt4(a.y + (size_t)m * 128 + pass * 64 + wn * 32 + c4, v);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2);
+      if (m < M) {
+        const float va = acc0[r] + bias_a, vb = acc1[r] + bias_b;
+        if (a.y) {
+          a.y[(size_t)m * 128 + ch] = va;
+          a.y[(size_t)m * 128 + 64 + ch] = vb;
+        }
+        float o = act_fwd(va, a.act) * sigmoidf_(vb);
+        if (a.res) o += rv[r];
+        a.out[(size_t)m * 64 + ch] = o;
+        const float dl = o - piv;
+        st1 += dl;
+        st2 += dl * dl;
+      }
+    }
+    if (has_next) store_a(As[cur ^ 1]);
+    __syncthreads();  // tile i+1 is in LDS; buffer `cur` is free again from the NEXT iteration's store on
+    cur ^= 1;
+  }
+
+  if (a.stats_out) {  // lanes, then the two row waves, in a fixed order: one row of partials per workgroup
+    if (WT) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sv1[j] += __shfl_xor(sv1[j], o, 64);
+          sv2[j] += __shfl_xor(sv2[j], o, 64);
+        }
+      if (lane < 8) {
+        *reinterpret_cast<f32x4*>(&red[0][wm][wn * 32 + c4]) = sv1;
+        *reinterpret_cast<f32x4*>(&red[1][wm][wn * 32 + c4]) = sv2;
+      }
+    } else {
+      st1 += __shfl_xor(st1, 32, 64);
+      st2 += __shfl_xor(st2, 32, 64);
+      if (lh == 0) {
+        red[0][wm][ch] = st1;
+        red[1][wm][ch] = st2;
+      }
+    }
+    __syncthreads();
+    if (t < 128) {
+      const int c = t & 63, which = t >> 6;
+      a.stats_out[((size_t)blockIdx.x * 2 + which) * 64 + c] = red[which][0][c] + red[which][1][c];
+      // the pivot travels with the partials (row gridDim.x): a consumer that finalizes them in its own prologue (lvae_bn_fold) must not
+      // depend on a buffer it updates itself
+      if (blockIdx.x == 0 && which == 0) a.stats_out[((size_t)gridDim.x * 2) * 64 + c] = a.stats_pivot[c];
+    }
+  }
+}
+
+// workgroups the persistent kernel runs for this descriptor (== rows of BatchNorm partials it writes); 0: not this kernel
+int conv1x1_gate_fwd_wgs(const lvae_conv_desc* d) {
+  static const bool off = getenv("LVAE_DISABLE_GATE_FWD_PERSISTENT") != nullptr;  // A/B switch, profiling only
+  static const int max_wgs = getenv("LVAE_GATE_FWD_WGS") ? atoi(getenv("LVAE_GATE_FWD_WGS")) : 512;  // tuning switch
+  static const int64_t min_m = getenv("LVAE_GATE_FWD_MIN_M") ? atoll(getenv("LVAE_GATE_FWD_MIN_M")) : 0;  // tuning switch
+  if (off || d == nullptr) return 0;
+  if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W || d->gather != LVAE_GATHER_CONV) return 0;
+  if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->Cout != 128) return 0;
+  if (d->in_scale != nullptr || d->in_fold != nullptr || d->out_scale != nullptr || d->out_act != LVAE_ACT_NONE) return 0;
+  if (d->x == nullptr || (reinterpret_cast<uintptr_t>(d->x) & 15) != 0) return 0;
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  if (M < min_m || M >= ((int64_t)1 << 31) - 64) return 0;
+  const int64_t tiles = (M + GF_BM - 1) / GF_BM;
+  const int cap = max_wgs > 0 ? max_wgs : 512;
+  return (int)(tiles < cap ? tiles : cap);
+}
+
+// -1000: not eligible (the caller uses conv1x1_kernel)
+int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, int act, hipStream_t s) {
+  const int wgs = conv1x1_gate_fwd_wgs(d);
+  if (wgs == 0 || out == nullptr) return -1000;
+  GateFwdArgs a;
+  a.x = d->x;
+  a.w = d->w;
+  a.w_sk = d->w_sk;
+  a.w_sn = d->w_sn;
+  a.bias = d->bias;
+  a.res = res;
+  a.y = d->y;
+  a.out = out;
+  a.stats_out = d->stats_out;
+  a.stats_pivot = d->stats_pivot;
+  a.M = (int)((int64_t)d->N * d->H * d->W);
+  a.tiles = (a.M + GF_BM - 1) / GF_BM;
+  a.act = act;
+  static const bool wt = getenv("LVAE_GATE_FWD_WT") == nullptr || atoi(getenv("LVAE_GATE_FWD_WT")) != 0;  // A/B switch, profiling only
+  const bool al = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d->y) |
+                    reinterpret_cast<uintptr_t>(d->stats_pivot)) & 15) == 0;
+  if (wt && al) hipLaunchKernelGGL(conv1x1_gate_fwd_kernel<true>, dim3(wgs), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv1x1_gate_fwd_kernel<false>, dim3(wgs), dim3(256), 0, s, a);
+  LVAE_LAUNCH_CHECK("conv1x1_gate_fwd");
+  return 0;
+}
+
+}  // namespace lvae

@@ -482,7 +482,7 @@ struct BfWgArgs {
   const float* dy;
   float* slab_w;   // [nwg][9][Cin][Cout]
   float* slab_b;   // [nwg][Cout] or null
-  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntiles, Cin, bm;
+  int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntiles, Cin, bm, split;
   uint32_t m_thw, m_tw, m_per_img, m_halo_w, m_tiles_h;
 };
 
@@ -495,12 +495,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int MI>  // tile = 64 * MI pixels
+// SPLIT = 1: bf16 operands. SPLIT = 3: both operands split exactly into three bf16 pieces and the six piece products of order <= 2^-16
+// accumulated (conv3x3_bf16_kernel's fp32-equivalent form). Unlike the forward kernel this one is bound by its slab traffic, not by
+// MFMAs (40 per wave and tile); the six-fold matrix work of SPLIT = 3 was hoped to hide under the memory time but does not (bfwg_form
+// below has the measurement), so SPLIT = 3 is an opt-in form that the parity tests keep exercised.
+template <int MI, int SPLIT>  // tile = 64 * MI pixels
 __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   constexpr int BM = 64 * MI, LDK = BF_LDK, KS = BM / 16;   // k-steps of 16 pixels per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* Xs = reinterpret_cast<__bf16*>(smem_raw);          // [halo_px][LDK]
-  __bf16* Ds = Xs + (size_t)a.halo_px * LDK;                  // [BM][LDK]
+  __bf16* Xs = reinterpret_cast<__bf16*>(smem_raw);          // [SPLIT][halo_px][LDK]
+  const int x_plane = a.halo_px * LDK;
+  __bf16* Ds = Xs + (size_t)SPLIT * x_plane;                  // [SPLIT][BM][LDK]
+  constexpr int d_plane = BM * LDK;
+  constexpr int UNR = SPLIT == 1 ? 2 : 1;  // k-steps in flight (register budget)
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cih = wave & 1, coh = (wave >> 1) & 1, tg = wave >> 2;   // ci half, co half, tap group
@@ -582,9 +589,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
           w = xr[u];
           if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
         }
-        bf16x4 pl[1];
-        split4<1>(w, pl);
-        *reinterpret_cast<bf16x4*>(Xs + px * LDK + c4) = pl[0];
+        bf16x4 pl[SPLIT];
+        split4<SPLIT>(w, pl);
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) *reinterpret_cast<bf16x4*>(Xs + q * x_plane + px * LDK + c4) = pl[q];
       }
     }
 #pragma unroll
@@ -592,24 +600,39 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
       const int p = px0 + 32 * u;
       const f32x4 w = ((dok >> u) & 1u) ? dr[u] : zero4;
       bsum += w;
-      bf16x4 pl[1];
-      split4<1>(w, pl);
-      *reinterpret_cast<bf16x4*>(Ds + p * LDK + c4) = pl[0];
+      bf16x4 pl[SPLIT];
+      split4<SPLIT>(w, pl);
+#pragma unroll
+      for (int q = 0; q < SPLIT; ++q) *reinterpret_cast<bf16x4*>(Ds + q * d_plane + p * LDK + c4) = pl[q];
     }
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
 
-#pragma unroll 2
+#pragma unroll UNR
     for (int s = 0; s < KS; ++s) {
       const int xr0 = xrow_of(s, 0), xr1 = xrow_of(s, 1);
-      const bf16x8 bfr = tr_frag(Ds + (16 * s + drow0) * LDK + chd, Ds + (16 * s + drow0 + 4) * LDK + chd);
+      bf16x8 bfr[SPLIT];
+#pragma unroll
+      for (int q = 0; q < SPLIT; ++q)
+        bfr[q] = tr_frag(Ds + q * d_plane + (16 * s + drow0) * LDK + chd, Ds + q * d_plane + (16 * s + drow0 + 4) * LDK + chd);
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         if (j < ntap) {
           const int tap = tap0 + j, kh = tap / 3, kw = tap - kh * 3;
           const int off = kh * a.halo_w + kw;
-          const bf16x8 afr = tr_frag(Xs + (xr0 + off) * LDK + chx, Xs + (xr1 + off) * LDK + chx);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
+          bf16x8 afr[SPLIT];
+#pragma unroll
+          for (int q = 0; q < SPLIT; ++q) afr[q] = tr_frag(Xs + q * x_plane + (xr0 + off) * LDK + chx, Xs + q * x_plane + (xr1 + off) * LDK + chx);
+          if (SPLIT == 1) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], acc[j], 0, 0, 0);
+          } else {  // smallest terms first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[SPLIT - 1], bfr[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[SPLIT - 1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1], bfr[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1], bfr[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], acc[j], 0, 0, 0);
+          }
         }
       }
     }
@@ -849,9 +872,24 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
 }
 
 // ---- bf16 weight gradient: host side
-static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
+// 0: not this kernel; 1: bf16 operands (precision LVAE_PREC_BF16); 3: fp32-equivalent six-product split for precision LVAE_PREC_F32,
+// only with LVAE_F32_SPLIT_WGRAD=1 and on layers of at least 32768 pixels. Measured on the CIFAR-15 step: 39.5 ms with it against 37.9 ms
+// with the Winograd-domain fp32 kernel (the six-fold matrix work is not hidden behind the slab traffic because staging and MFMAs alternate
+// on one LDS buffer), so the default keeps every fp32 gradient on the fp32 MFMA; the parity tests run both forms.
+static int bfwg_form(const lvae_conv_desc* d) {
   static const bool off = getenv("LVAE_DISABLE_BF16_WGRAD") != nullptr;  // A/B switch, profiling only
-  if (off || d->precision != LVAE_PREC_BF16) return false;
+  if (off) return 0;
+  if (d->precision == LVAE_PREC_BF16) return 1;
+  const char* sw = getenv("LVAE_F32_SPLIT_WGRAD");  // A/B switch, read per call (the parity tests run both forms in one process)
+  if (sw == nullptr || atoi(sw) == 0) return 0;
+  static const int64_t min_m = getenv("LVAE_F32_SPLIT_WGRAD_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_WGRAD_MIN_M")) : 32768;  // tuning switch
+  return (int64_t)d->N * d->H * d->W >= min_m ? 3 : 0;
+}
+
+static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
+  const int split = bfwg_form(d);
+  if (split == 0) return false;
+  a.split = split;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->gather != LVAE_GATHER_CONV || d->x2 != nullptr) return false;
   if (d->OH != d->H || d->OW != d->W || d->C1 > 64 || d->C1 % 4 != 0 || d->Cout % 4 != 0) return false;
   if (!al16b(d->x) || !al16b(d->in_scale) || !al16b(d->in_shift)) return false;
@@ -865,6 +903,7 @@ static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
     if (!bf_plan_bm(d, 1, 64, g) || g.halo_px > 224 || (g.NI * g.TH * g.TW) % 16 != 0) return false;
   }
   if (g.NI * g.TH * g.TW != bm) return false;   // whole 16-pixel k-steps only (image widths 8, 16, 32 ...)
+  if ((size_t)split * (g.halo_px + bm) * BF_LDK * 2 > 160 * 1024) return false;
   a.TH = g.TH; a.TW = g.TW; a.NI = g.NI; a.tiles_h = g.tiles_h; a.halo_w = g.halo_w; a.halo_h = g.halo_h; a.halo_px = g.halo_px;
   a.m_thw = g.m_thw; a.m_tw = g.m_tw; a.m_per_img = g.m_per_img; a.m_halo_w = g.m_halo_w; a.m_tiles_h = fastdiv_magic(g.tiles_h);
   a.ntiles = ((d->N + g.NI - 1) / g.NI) * g.tiles_h;
@@ -902,11 +941,26 @@ int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, 
   const int nwg = bfwg_nwg(a);
   a.slab_w = static_cast<float*>(workspace);
   a.slab_b = db ? a.slab_w + (size_t)nwg * 9 * d->C1 * d->Cout : nullptr;
-  size_t lds = ((size_t)a.halo_px + a.bm) * BF_LDK * 2;
+  size_t lds = (size_t)a.split * (a.halo_px + a.bm) * BF_LDK * 2;
   if (lds < 32 * 64 * 4) lds = 32 * 64 * 4;
   const dim3 grid(nwg, (d->Cout + 63) / 64);
-  if (a.bm == 128) hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<2>, grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel<1>, grid, dim3(512), lds, s, a);
+  static std::atomic<bool> attr_set{false};  // idempotent attribute writes; the flag itself is race-free
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv3x3_wgrad_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  if (a.split == 1) {
+    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1>), grid, dim3(512), lds, s, a);
+  } else {
+    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 3>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 3>), grid, dim3(512), lds, s, a);
+  }
   LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16");
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 9, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
   LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16_reduce");

@@ -55,57 +55,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_grouped_kernel(WgWinoG
 #include "conv3x3_wgrad_wino_body.inc"
 }
 
-// dw[tap(a,b)][ci][co] += (G^T (sum_ranges slab) G)[a][b]; one 1024-thread workgroup per (ci, group of 64 co): threads =
-// 16 float4 columns x 16 positions x 4 range slices; each range contributes one contiguous 4 KB block; fixed summation order.
-__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(const float* __restrict__ slab_w, const float* __restrict__ slab_b,
-                                                                       int nranges, int ncog, int Cout, int64_t stap, int64_t sk,
-                                                                       int64_t sn, float* dw, float* db) {
-  __shared__ float red[4][16][64];
-  __shared__ float red_b[16][64];
-  const int ci = blockIdx.x / ncog, cog = blockIdx.x % ncog;
-  const int t = threadIdx.x, q = t & 15, p = (t >> 4) & 15, rs = t >> 8;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const float* src = slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + q * 4;
-  const size_t rstride = (size_t)2 * ncog * 32 * 16 * 64;
-#pragma unroll 8
-  for (int r = rs; r < nranges; r += 4) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
-  *reinterpret_cast<f32x4*>(&red[rs][p][q * 4]) = s;
-  const bool do_b = db != nullptr && ci == 0;
-  if (do_b) {
-    const int co = t & 63, slice = t >> 6;
-    float v = 0.f;
-#pragma unroll 4
-    for (int r = slice; r < nranges; r += 16) v += slab_b[(size_t)(r * ncog + cog) * 64 + co];
-    red_b[slice][co] = v;
-  }
-  __syncthreads();
-  if (t < 192 && cog * 64 + (t & 63) < Cout) {
-    const int co = t & 63, ga = t >> 6;  // output row a of G^T dU G
-    float u[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) u[i][j] = (red[0][i * 4 + j][co] + red[1][i * 4 + j][co]) + (red[2][i * 4 + j][co] + red[3][i * 4 + j][co]);
-    // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
-    float ra[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      ra[j] = ga == 0 ? u[0][j] + 0.5f * (u[1][j] + u[2][j]) : (ga == 1 ? 0.5f * (u[1][j] - u[2][j]) : 0.5f * (u[1][j] + u[2][j]) + u[3][j]);
-    const float g0 = ra[0] + 0.5f * (ra[1] + ra[2]), g1 = 0.5f * (ra[1] - ra[2]), g2 = 0.5f * (ra[1] + ra[2]) + ra[3];
-    float* o = dw + (int64_t)ci * sk + (int64_t)(cog * 64 + co) * sn + (int64_t)(ga * 3) * stap;
-    o[0] += g0;
-    o[stap] += g1;
-    o[2 * stap] += g2;
-  }
-  if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < Cout) {
-    const int co = t - 256;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v += red_b[k][co];
-    db[cog * 64 + co] += v;
-  }
-}
-
 struct WinoReduceArgs {
   const float* slab_w;
   const float* slab_b;
@@ -118,21 +67,39 @@ struct WinoReduceGroup {
   WinoReduceArgs p[kMaxWinoGroup];
 };
 
-__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(WinoReduceGroup g) {
-  const WinoReduceArgs& a = g.p[blockIdx.y];
-  if ((int)blockIdx.x >= 64 * a.ncog) return;
-  __shared__ float red[4][16][64];
-  __shared__ float red_b[16][64];
+// dw[tap(a,b)][ci][co] += (G^T (sum_ranges slab) G)[a][b], 1024-thread workgroups, ranges summed in eight slices (slice = range mod 8,
+// ascending inside a slice, then a balanced tree over the slices: the same order in both forms, so they agree bitwise).
+//   HALF (single gradient): workgroup = (ci, half of a group of 64 co), threads = 8 float4 columns x 16 positions x 8 slices, so each
+//     range contributes sixteen 128-byte pieces (whole cache lines). 128 workgroups per 64x64 gradient instead of 64: the pass is bound
+//     by how many bytes a CU keeps in flight, not by HBM (64 workgroups: 9.7 us for 33.5 MB, 128: 9.0 us; 256 workgroups of 64-byte
+//     pieces: 31 us).
+//   !HALF (grouped launch, up to 12 gradients = 768 workgroups already): workgroup = (ci, 64 co), threads = 16 float4 columns x
+//     16 positions x 4, each carrying two slices; halving these workgroups as well cost 12 us per launch.
+template <bool HALF>
+__device__ __forceinline__ void wino_reduce_body(const WinoReduceArgs& a, int bx, float* red, float (*red_b)[64]) {
+  constexpr int CW = HALF ? 32 : 64;   // output channels per workgroup; red is [8][16][CW]
   const int ncog = a.ncog, nranges = a.nranges;
-  const int ci = blockIdx.x / ncog, cog = blockIdx.x % ncog;
-  const int t = threadIdx.x, q = t & 15, p = (t >> 4) & 15, rs = t >> 8;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const float* src = a.slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + q * 4;
+  const int half = HALF ? (bx & 1) : 0, cc = HALF ? (bx >> 1) : bx, ci = cc / ncog, cog = cc % ncog;
+  const int t = threadIdx.x;
+  const int q = HALF ? (t & 7) : (t & 15), p = HALF ? ((t >> 3) & 15) : ((t >> 4) & 15), rs = HALF ? (t >> 7) : (t >> 8);
+  const float* src = a.slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + half * 32 + q * 4;
   const size_t rstride = (size_t)2 * ncog * 32 * 16 * 64;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (HALF) {
 #pragma unroll 8
-  for (int r = rs; r < nranges; r += 4) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
-  *reinterpret_cast<f32x4*>(&red[rs][p][q * 4]) = s;
-  const bool do_b = a.db != nullptr && ci == 0;
+    for (int r = rs; r < nranges; r += 8) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+    *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
+  } else {
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int r = rs; r < nranges; r += 8) {
+      s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+      if (r + 4 < nranges) s1 += *reinterpret_cast<const f32x4*>(src + (r + 4) * rstride);
+    }
+    *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
+    *reinterpret_cast<f32x4*>(red + ((rs + 4) * 16 + p) * CW + q * 4) = s1;
+  }
+  const bool do_b = a.db != nullptr && ci == 0 && half == 0;
   if (do_b) {
     const int co = t & 63, slice = t >> 6;
     float v = 0.f;
@@ -141,19 +108,23 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(Wi
     red_b[slice][co] = v;
   }
   __syncthreads();
-  if (t < 192 && cog * 64 + (t & 63) < a.Cout) {
-    const int co = t & 63, ga = t >> 6;
+  if (t < 3 * CW && cog * 64 + half * 32 + (t % CW) < a.Cout) {
+    const int co = t % CW, ga = t / CW;  // output row a of G^T dU G
     float u[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) u[i][j] = (red[0][i * 4 + j][co] + red[1][i * 4 + j][co]) + (red[2][i * 4 + j][co] + red[3][i * 4 + j][co]);
+      for (int j = 0; j < 4; ++j) {
+        const float* rp = red + (i * 4 + j) * CW + co;
+        u[i][j] = ((rp[0] + rp[16 * CW]) + (rp[32 * CW] + rp[48 * CW])) + ((rp[64 * CW] + rp[80 * CW]) + (rp[96 * CW] + rp[112 * CW]));
+      }
+    // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
     float ra[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       ra[j] = ga == 0 ? u[0][j] + 0.5f * (u[1][j] + u[2][j]) : (ga == 1 ? 0.5f * (u[1][j] - u[2][j]) : 0.5f * (u[1][j] + u[2][j]) + u[3][j]);
     const float g0 = ra[0] + 0.5f * (ra[1] + ra[2]), g1 = 0.5f * (ra[1] - ra[2]), g2 = 0.5f * (ra[1] + ra[2]) + ra[3];
-    float* o = a.dw + (int64_t)ci * a.sk + (int64_t)(cog * 64 + co) * a.sn + (int64_t)(ga * 3) * a.stap;
+    float* o = a.dw + (int64_t)ci * a.sk + (int64_t)(cog * 64 + half * 32 + co) * a.sn + (int64_t)(ga * 3) * a.stap;
     o[0] += g0;
     o[a.stap] += g1;
     o[2 * a.stap] += g2;
@@ -165,6 +136,20 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(Wi
     for (int k = 0; k < 16; ++k) v += red_b[k][co];
     a.db[cog * 64 + co] += v;
   }
+}
+
+__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(WinoReduceArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 16 * 32];
+  __shared__ float red_b[16][64];
+  wino_reduce_body<true>(a, blockIdx.x, red, red_b);
+}
+
+__global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(WinoReduceGroup g) {
+  const WinoReduceArgs& a = g.p[blockIdx.y];
+  if ((int)blockIdx.x >= 64 * a.ncog) return;   // uniform per workgroup, before any barrier
+  __shared__ __attribute__((aligned(16))) float red[8 * 16 * 64];
+  __shared__ float red_b[16][64];
+  wino_reduce_body<false>(a, blockIdx.x, red, red_b);
 }
 
 static bool al16g(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -236,8 +221,8 @@ int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, flo
   else if (d->W == 16) rc = launch_wg_wino<8>(a, s);
   else rc = launch_wg_wino<16>(a, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(64 * a.ncog), dim3(1024), 0, s, a.slab_w, a.slab_b, a.nranges,
-                     a.ncog, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db);
+  const WinoReduceArgs ra{a.slab_w, a.slab_b, a.nranges, a.ncog, d->Cout, 0, d->w_stap, d->w_sk, d->w_sn, dw, db};
+  hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(128 * a.ncog), dim3(1024), 0, s, ra);
   LVAE_LAUNCH_CHECK("conv_wgrad_wino_reduce");
   return 0;
 }

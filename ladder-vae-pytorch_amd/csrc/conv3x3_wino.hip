@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           v = v + bias;
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
-          *reinterpret_cast<f32x4*>(yb + (size_t)p * d.Cout) = v;
+          store_wt4(yb + (size_t)p * d.Cout, v);
           if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);

@@ -367,6 +367,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d);
 bool conv3x3_wino_eligible(const lvae_conv_desc* d);
 int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s);
+int conv1x1_gate_fwd_wgs(const lvae_conv_desc* d);
+int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, int act, hipStream_t s);
 int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
                    const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s);
 
@@ -466,6 +468,8 @@ extern "C" int lvae_conv2d_bf16(const lvae_conv_desc* d, void* stream) {
 // rows of BatchNorm partials ([rows][2][C], C = Cout/2) lvae_conv1x1_gate_f32 writes for its `out` when d->stats_out is set
 extern "C" int32_t lvae_conv1x1_gate_stats_rows(const lvae_conv_desc* d) {
   if (d == nullptr || d->Cout % 8 != 0) return 0;
+  const int persistent = conv1x1_gate_fwd_wgs(d);  // one row per workgroup of the persistent kernel (conv1x1_gate_fwd.hip)
+  if (persistent) return persistent;
   const int c4n = d->Cout / 8;
   if (c4n <= 0 || 256 % c4n != 0 || d->Cout > 128) return 0;
   return (int32_t)(((int64_t)d->N * d->H * d->W + 63) / 64);  // 64-pixel tiles
@@ -479,7 +483,8 @@ extern "C" int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, 
   LVAE_REQUIRE(d->stats_out == nullptr || (d->stats_pivot != nullptr && lvae_conv1x1_gate_stats_rows(d) > 0 &&
                                            (reinterpret_cast<uintptr_t>(d->stats_pivot) & 15) == 0),
                LVAE_EINVAL, "lvae_conv1x1_gate_f32: stats_out set but lvae_conv1x1_gate_stats_rows(d) == 0");
-  rc = conv1x1_try(d, res, out, act, (hipStream_t)stream);
+  rc = conv1x1_gate_fwd_try(d, res, out, act, (hipStream_t)stream);
+  if (rc == -1000) rc = conv1x1_try(d, res, out, act, (hipStream_t)stream);
   LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
                "lvae_conv1x1_gate_f32: unsupported shape (needs a 1x1 stride-1 conv, Cin <= 128, Cout <= 128, channels %% 4 == 0, "
                "16-byte aligned buffers); use lvae_conv2d_f32 + lvae_gate_fwd_f32");

@@ -47,6 +47,25 @@ inline int debug_phase_switch(const char* name) {
     }                                                                  \
   } while (0)
 
+// 16-byte store of a large output tensor as a write-through (sc1) store. Plain stores leave the lines dirty in the XCD's L2 until the
+// end of the kernel, whose release then writes them back in one go, after the last wave (about bytes / 6 TB/s: ~3 us behind the
+// 16.8 MB of a 256x16x16x64 tensor; MI355X_MICROARCH.md, "boundary" and "publish-large"). Written through, the bytes drain
+// while the kernel is still computing. The next kernel reads them from memory / Infinity Cache either way (the L2s are not coherent
+// across XCDs and are invalidated at its start), so dropping the line costs nothing. 16-byte stores only: narrower sc1 stores are one
+// fabric write each. -DLVAE_WT_STORES=0 restores plain stores (A/B builds).
+#ifndef LVAE_WT_STORES
+#define LVAE_WT_STORES 1
+#endif
+__device__ __forceinline__ void store_wt4(float* p, f32x4 v) {
+#if LVAE_WT_STORES
+  // s_nop: a VALU write to the data registers of a store wider than 8 bytes needs two wait states after it on gfx940+ (LLVM GCNHazardRecognizer, VMEM store hazard); the compiler's hazard
+  // recognizer inserts that for its own stores but cannot see into inline asm (found the hard way: corrupted lanes)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
 

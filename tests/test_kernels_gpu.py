@@ -115,6 +115,7 @@ def test_conv3x3_winograd(K, case, form, monkeypatch):
     products per fp32 product on the bf16 MFMA (the default where the shape fits); both must agree with the direct sum to a few
     ulp of fp32, including the fused BN/activation prologue and dropout/activation epilogue."""
     monkeypatch.setenv('LVAE_F32_SPLIT', '0' if form == 'winograd' else '1')
+    monkeypatch.setenv('LVAE_F32_SPLIT_WGRAD', '0' if form == 'winograd' else '1')   # weight gradient: fp32 MFMA / six-product bf16 form
     N, Co, H, W = case
     C = 64
     g = torch.Generator().manual_seed(sum(case))
@@ -286,7 +287,9 @@ def test_bn_stats_and_affine_bwd(K, shape):
     assert rel(dg.cpu(), gamma.grad) < 1e-5 and rel(db.cpu(), beta.grad) < 1e-5
 
 
-@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (2, 8, 2, 2), (70, 32, 8, 8)])
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (2, 8, 2, 2), (70, 32, 8, 8),
+                                   (129, 64, 16, 16),   # persistent kernel: 516 tiles over 512 workgroups (four of them take two)
+                                   (37, 64, 3, 3)])     # ... ragged last tile
 def test_conv1x1_gate_fused(K, shape):
     N, C, H, W = shape
     g = torch.Generator().manual_seed(11)
@@ -298,6 +301,9 @@ def test_conv1x1_gate_fused(K, shape):
     wp = packed_weight(w)
     abd, outd = K.conv1x1_gate(nhwc(x), wp, K.ConvGeom(wp, 1, 0), b.cuda(), nhwc(res), 'elu')
     assert rel(nchw(abd), ab) < 2e-6 and rel(nchw(outd), out) < 2e-6
+    # without the pre-activations (evaluation) and without a residual
+    abn, outn = K.conv1x1_gate(nhwc(x), wp, K.ConvGeom(wp, 1, 0), b.cuda(), None, 'elu', need_ab=False)
+    assert abn is None and rel(nchw(outn), out - res) < 2e-6
 
 
 @pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8), (5, 8, 2, 2)])
@@ -361,7 +367,7 @@ def test_bn_statistics_from_conv_epilogue(K, case):
     assert torch.equal(y, K.conv2d(x, wp, geom, bias=b, out_scale=drop))
 
 
-@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8)])
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8), (129, 64, 16, 16), (37, 64, 3, 3)])
 def test_bn_statistics_from_gate_epilogue(K, shape):
     """conv1x1_gate(..., stats_pivot) + bn_finalize_parts == bn_stats on the gate output (the next block's BatchNorm input)."""
     N, C, H, W = shape

@@ -1,0 +1,18 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu > gpurun_out/gate_tests.log 2>&1 && \
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-bf16-line > gpurun_out/gate_on.log 2>&1 && \
+LVAE_GATE_FWD_WGS=256 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-bf16-line > gpurun_out/gate_256.log 2>&1 && \
+LVAE_GATE_FWD_MIN_M=16384 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-bf16-line > gpurun_out/gate_min16k.log 2>&1 && \
+LVAE_DISABLE_GATE_FWD_PERSISTENT=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-bf16-line > gpurun_out/gate_off.log 2>&1 && \
+rm -rf gpurun_out/gate_prof && rocprofv3 --kernel-trace -d gpurun_out/gate_prof -o g -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --no-bf16-line > gpurun_out/gate_prof.log 2>&1
+echo rc=$?
+tail -3 gpurun_out/gate_tests.log
+for f in gate_on gate_256 gate_min16k gate_off; do grep -h ms_per_step gpurun_out/$f.log | python -c "
+import sys, json
+for l in sys.stdin:
+    print('$f', json.loads(l)['ms_per_step'])"; done
+db=$(find gpurun_out/gate_prof -name "*.db" | head -1)
+python tools/db_agg.py $db "" 45 > gpurun_out/gate_by_grid.txt
+rm -rf gpurun_out/gate_prof
