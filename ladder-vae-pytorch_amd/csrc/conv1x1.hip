@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
         vb += *reinterpret_cast<const f32x4*>(d.bias + C + c);
       }
       if (d.y) {
-        *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = va;
-        *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + C + c) = vb;
+        store_wt4(d.y + (size_t)m * N + c, va);
+        store_wt4(d.y + (size_t)m * N + C + c, vb);
       }
       f32x4 o = act_fwd4(va, a.gate_act);
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       } else if (a.gate_res) {
         o += *reinterpret_cast<const f32x4*>(a.gate_res + (size_t)m * C + c);
       }
-      *reinterpret_cast<f32x4*>(a.gate_out + (size_t)m * C + c) = o;
+      store_wt4(a.gate_out + (size_t)m * C + c, o);
       const f32x4 dl = o - piv;
       st1 += dl;
       st2 += dl * dl;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + c);
       if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(m / a.ohw) * N + c);
       v = act_fwd4(v, d.out_act);
-      *reinterpret_cast<f32x4*>(d.y + (size_t)m * N + c) = v;
+      store_wt4(d.y + (size_t)m * N + c, v);
     }
   }
 }

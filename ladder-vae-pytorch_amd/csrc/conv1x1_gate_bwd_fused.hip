@@ -14,6 +14,15 @@
 // both read the same dab tile); the raw operands of the next tile are prefetched into registers while the MFMAs run. HBM traffic per gated block drops
 // from 150 MB to 84 MB and one launch disappears. Per-workgroup weight-gradient partials go to the usual split-K slabs
 // ([workgroup][64][128] + [workgroup][128]) and are summed in a fixed order (wgrad_reduce_launch): deterministic.
+//
+// Where the 33.7 us at 256x16x16 go (phase-skip builds, round 2): 15.8 us are the 128 fp32 MFMAs per tile and SIMD (13.6 us at 2.4 GHz),
+// 6.2 us the gate arithmetic, 2.3 us the dx stores, 1.6 us operand fetch that the prefetch does not hide, the rest launch, prologue and
+// the slab write. Two restructurings were built and measured, and neither is kept:
+//   * one barrier per tile (double-buffered dab / y tiles, W in registers, dx through wave-private LDS strips): 35.8 us against 35.2 us;
+//   * twelve waves with the gate arithmetic on four producer waves (one per SIMD, beside a dgrad and a weight-gradient wave): 38.6 us.
+//     Alone the producers need 1.8 us per tile and the MFMA waves 3.2 us; together a tile takes 5.9 us - more than their sum.
+//     v_mfma_f32_32x32x2_f32 and the vector ALU do not overlap on this chip (the fp32 matrix rate equals the packed-fp32 vector rate:
+//     the same lanes), so in an fp32 kernel VALU time adds to MFMA time whichever wave issues it. The bf16 MFMAs have their own unit.
 #include "lvae_common.h"
 
 namespace lvae {
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
       if (m < a.M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
         if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
-        *reinterpret_cast<f32x4*>(a.dx + (size_t)m * 64 + c4) = v;
+        store_wt4(a.dx + (size_t)m * 64 + c4, v);
       }
     }
     __syncthreads();  // staging tile is read: the next iteration overwrites it

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
           v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
         }
         v = act_fwd4(v, d.out_act);
-        *reinterpret_cast<f32x4*>(yp + (size_t)q * 16 * d.Cout) = v;
+        store_wt4(yp + (size_t)q * 16 * d.Cout, v);
         if (d.stats_mode == LVAE_STATS_BN_BWD) {
           if (d.stats_out) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16p_kernel(BfArgs a) {
             v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
           }
           v = act_fwd4(v, d.out_act);
-          *reinterpret_cast<f32x4*>(yp + (size_t)q * 16 * d.Cout) = v;
+          store_wt4(yp + (size_t)q * 16 * d.Cout, v);
           if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
