@@ -1,0 +1,30 @@
+// bf16 MFMA operand helpers shared by the bf16-precision kernels (gfx950 only).
+#pragma once
+#include "lvae_common.h"
+
+namespace lvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Two transposed 4 x 16 blocks of a [row][channel] bf16 image in LDS -> the 8 consecutive rows (the MFMA's k) of this lane's channel:
+// ds_read_b64_tr_b16 hands a 4-row x 16-channel block to 16 lanes channel-major (the hardware transpose; semantics probed on the device
+// with tools/tr_probe.hip). For k-step s (16 rows) and a 32-channel block at channel cb, lane (G = lane >> 4, i16 = lane & 15) passes
+//   p0 = image + (16 s + 8 (G >> 1) + (i16 >> 2)) * pitch + cb + 16 (G & 1) + 4 (i16 & 3),   p1 = p0 + 4 * pitch
+// and receives rows 16 s + 8 (lane >> 5) + 0..7 of channel cb + (lane & 31): the A (or B) fragment of v_mfma_f32_32x32x16_bf16.
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 lo, const f32x4 hi) {
+  return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+}
+
+}  // namespace lvae

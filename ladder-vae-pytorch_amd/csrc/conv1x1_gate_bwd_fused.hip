@@ -23,6 +23,7 @@
 //     Alone the producers need 1.8 us per tile and the MFMA waves 3.2 us; together a tile takes 5.9 us - more than their sum.
 //     v_mfma_f32_32x32x2_f32 and the vector ALU do not overlap on this chip (the fp32 matrix rate equals the packed-fp32 vector rate:
 //     the same lanes), so in an fp32 kernel VALU time adds to MFMA time whichever wave issues it. The bf16 MFMAs have their own unit.
+#include "bf16_frag.h"
 #include "lvae_common.h"
 
 namespace lvae {
@@ -181,6 +182,149 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
   }
 }
 
+// The same kernel for precision = LVAE_PREC_BF16: dab, y and W are rounded to bf16 where they enter the matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate); the gate derivative itself, the bias gradient and everything that leaves the kernel stay
+// fp32. The fp32 kernel's 15.8 us of MFMA time (which VALU work cannot hide under, see above) shrink to under 1 us on the bf16 unit,
+// which does run beside the vector ALU. dab / y tiles are [pixel][channel] bf16 images; the dgrad reads its A fragments row-wise
+// (ds_read_b128, W fragments in 32 registers per dgrad wave), the weight gradient needs 8 consecutive PIXELS of one channel per lane
+// for both operands and reads them with the transposing ds_read_b64_tr_b16 (bf16_frag.h), as conv3x3_wgrad_bf16_kernel does.
+constexpr int GBB_LDA = 136;  // dab row pitch in bf16 (128 channels + 8: 272 bytes, 16-byte multiples for ds_read_b128)
+constexpr int GBB_LDY = 72;   // y row pitch in bf16
+constexpr size_t GBB_LDS = (size_t)64 * GBB_LDA * 2 + (size_t)64 * GBB_LDY * 2 + (size_t)64 * GB_LDY * 4;
+
+__global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [64 px][136]: dab tile
+  __bf16* Ys = As + 64 * GBB_LDA;                                    // [64 px][72]: y tile
+  float* Os = reinterpret_cast<float*>(Ys + 64 * GBB_LDY);           // [64 px][68]: dx staging (fp32)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool wg_role = wave >= 4;  // waves 4-7: weight gradient; waves 0-3: dgrad
+  const int wm = (wave & 3) >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5, G = lane >> 4, i16 = lane & 15;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s
+  bf16x8 breg[8];
+  if (!wg_role) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float* wp = a.w + (int64_t)(wn * 32 + li) * a.w_sn + 16 * s + 8 * lh;
+      breg[s] = to_bf16x8(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4));
+    }
+  }
+
+  constexpr int IT = 2;
+  f32x4 pg[IT], pa[IT], pb[IT], py[IT];
+  const int c4 = (t & 15) * 4, r0 = t >> 4;
+  auto prefetch = [&](int tile) {
+    const int m0 = tile * 64;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int m = m0 + r0 + 32 * u;
+      const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
+      pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
+      pa[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + c4);
+      pb[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + 64 + c4);
+      py[u] = *reinterpret_cast<const f32x4*>(a.y + mc * 64 + c4);
+    }
+  };
+
+  f32x16 accw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+  f32x4 bs_lo = zero4, bs_hi = zero4;  // bias-gradient partials (fp32 dab, not the rounded operand)
+  // transposed-read addresses of this lane (bf16_frag.h): pixel row 8 (G >> 1) + (i16 >> 2) of a k-step, channel 16 (G & 1) + 4 (i16 & 3) of a block
+  const int trow = 8 * (G >> 1) + (i16 >> 2), tch = 16 * (G & 1) + 4 * (i16 & 3);
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    const int m0 = tile * 64;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int r = r0 + 32 * u;
+      f32x4 lo = zero4, hi = zero4, yv = zero4;
+      if (m0 + r < a.M) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sg = sigmoidf_(pb[u][j]);
+          lo[j] = pg[u][j] * sg * act_grad(pa[u][j], a.act);
+          hi[j] = pg[u][j] * act_fwd(pa[u][j], a.act) * sg * (1.f - sg);
+        }
+        yv = py[u];
+      }
+      bs_lo += lo;
+      bs_hi += hi;
+      *reinterpret_cast<bf16x4*>(As + r * GBB_LDA + c4) = to_bf16x4(lo);
+      *reinterpret_cast<bf16x4*>(As + r * GBB_LDA + 64 + c4) = to_bf16x4(hi);
+      *reinterpret_cast<bf16x4*>(Ys + r * GBB_LDY + c4) = to_bf16x4(yv);
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+
+    if (!wg_role) {
+      // ---- dgrad: dx[32 px (wm)][32 ci (wn)] = dab[px][0:128] . W, 8 k-steps of 16
+      f32x16 accx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + li) * GBB_LDA + 16 * s + 8 * lh);
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, breg[s], accx, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
+    } else {
+      // ---- weight gradient: dW[32 ci (wn)][2 x 32 co (wm)] += y^T . dab, k = pixel: 4 k-steps of 16 pixels
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const __bf16* yp = Ys + (16 * s + trow) * GBB_LDY + wn * 32 + tch;
+        const bf16x8 af = tr_frag(yp, yp + 4 * GBB_LDY);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const __bf16* dp = As + (16 * s + trow) * GBB_LDA + (wm * 2 + j) * 32 + tch;
+          const bf16x8 bf = tr_frag(dp, dp + 4 * GBB_LDA);
+          accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accw[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // dab / y tiles are dead (the next iteration overwrites them), the dx staging tile is complete
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int r = r0 + 32 * u, m = m0 + r;
+      if (m < a.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
+        if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
+        store_wt4(a.dx + (size_t)m * 64 + c4, v);
+      }
+    }
+    // no barrier here: the next write to the staging tile comes after the next iteration's first barrier
+  }
+
+  float* sw = a.slab_w + (size_t)blockIdx.x * 64 * 128;
+  if (wg_role) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sw[(size_t)(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + (wm * 2 + j) * 32 + li] = accw[j][r];
+  }
+  if (a.slab_b) {
+    __syncthreads();  // the last tile's dx staging reads are done
+    float* red = Os;  // [32 row groups][128] floats = 16 KB <= the 17 KB staging tile
+    *reinterpret_cast<f32x4*>(red + r0 * 128 + c4) = bs_lo;
+    *reinterpret_cast<f32x4*>(red + r0 * 128 + 64 + c4) = bs_hi;
+    __syncthreads();
+    if (t < 128) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) v += red[g * 128 + t];
+      a.slab_b[(size_t)blockIdx.x * 128 + t] = v;
+    }
+  }
+}
+
 static bool al16f(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // workgroups (= weight-gradient slabs) for M pixels: one per CU, fewer when there are fewer tiles
@@ -231,7 +375,8 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
+  if (d->precision == LVAE_PREC_BF16) hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel, dim3(nwg), dim3(512), GBB_LDS, s, a);
+  else hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
   LVAE_LAUNCH_CHECK("conv1x1_gate_bwd_fused");
   // slabs are [nwg][ci][co]: the gate convolution's weight element (ci, co) lives at dw[ci * dw_sk + co * dw_sn]
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 1, 64, 128, 0, dw_sk, dw_sn, dw, db, s);

@@ -15,6 +15,7 @@
 //     before the MFMAs of their tile.
 #include <stdlib.h>
 
+#include "bf16_frag.h"
 #include "lvae_common.h"
 
 namespace lvae {
@@ -39,7 +40,11 @@ constexpr int GF_LDO = 40;  // staging row stride (floats): 4 rows = 160 = 32 mo
 // WT: the three outputs leave as 16-byte write-through stores (store_wt4), transposed from the accumulator layout through a 5 KB LDS
 // strip that belongs to the wave alone (no workgroup barrier: a wave's LDS instructions execute in order); the residual rows are
 // then fetched as float4 in the store layout. !WT: one dword per lane straight from the accumulators, plain stores.
-template <bool WT>
+// BF16 (precision = LVAE_PREC_BF16): x and W are rounded to bf16 where they enter the matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate): 8 MFMAs per wave and tile instead of 64, on a unit that runs beside the vector ALU; everything after the accumulators is
+// the fp32 code. The x tile is a [pixel][channel] bf16 image (pitch 72) in the same LDS buffers.
+constexpr int GF_LDB = 72;
+template <bool WT, bool BF16>
 __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][GF_BM * GF_LDA];
   __shared__ __attribute__((aligned(16))) float Os[WT ? 4 : 1][WT ? 32 * GF_LDO : 4];
@@ -63,22 +68,37 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
-      *reinterpret_cast<f32x4*>(dst + r * GF_LDA + k) = av[u];
+      if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + r * GF_LDB + k) = to_bf16x4(av[u]);
+      else *reinterpret_cast<f32x4*>(dst + r * GF_LDA + k) = av[u];
     }
   };
 
   int tile = blockIdx.x;
   load_a(tile);
   // B operands: k-step s = 4 g + j of group g multiplies A[.][8 g + 4 lh + j] (the four floats of this lane's ds_read_b128)
-  float breg[2][32];
+  // (BF16: k-step s of 16 multiplies A[.][16 s + 8 lh + 0..7], the eight bf16 of this lane's ds_read_b128)
+  float breg[2][BF16 ? 1 : 32];
+  bf16x8 bq[2][BF16 ? 4 : 1];
+  if (BF16) {
 #pragma unroll
-  for (int g = 0; g < 8; ++g)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t ko = (int64_t)(8 * g + 4 * lh + j) * a.w_sk;
-      breg[0][4 * g + j] = a.w[ko + (int64_t)ch * a.w_sn];
-      breg[1][4 * g + j] = a.w[ko + (int64_t)(64 + ch) * a.w_sn];
-    }
+      for (int ni = 0; ni < 2; ++ni) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = a.w[(int64_t)(16 * s + 8 * lh + j) * a.w_sk + (int64_t)(ni * 64 + ch) * a.w_sn];
+        bq[ni][s] = to_bf16x8(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+      }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t ko = (int64_t)(8 * g + 4 * lh + j) * a.w_sk;
+        breg[0][4 * g + j] = a.w[ko + (int64_t)ch * a.w_sn];
+        breg[1][4 * g + j] = a.w[ko + (int64_t)(64 + ch) * a.w_sn];
+      }
+  }
   const float bias_a = a.bias ? a.bias[ch] : 0.f, bias_b = a.bias ? a.bias[64 + ch] : 0.f;
   const float piv = a.stats_out ? a.stats_pivot[ch] : 0.f;
   float st1 = 0.f, st2 = 0.f;
@@ -117,14 +137,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    const float* arow = As[cur] + (wm * 32 + li) * GF_LDA + 4 * lh;
+    if (BF16) {
+      const __bf16* arow = reinterpret_cast<const __bf16*>(As[cur]) + (wm * 32 + li) * GF_LDB + 8 * lh;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * g);
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[1][s], acc1, 0, 0, 0);
+      }
+    } else {
+      const float* arow = As[cur] + (wm * 32 + li) * GF_LDA + 4 * lh;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[0][4 * g + j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[1][4 * g + j], acc1, 0, 0, 0);
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(arow + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[0][4 * g + j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], breg[1][4 * g + j], acc1, 0, 0, 0);
+        }
       }
     }
     if (WT) {
@@ -255,8 +285,14 @@ int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, 
   static const bool wt = getenv("LVAE_GATE_FWD_WT") == nullptr || atoi(getenv("LVAE_GATE_FWD_WT")) != 0;  // A/B switch, profiling only
   const bool al = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d->y) |
                     reinterpret_cast<uintptr_t>(d->stats_pivot)) & 15) == 0;
-  if (wt && al) hipLaunchKernelGGL(conv1x1_gate_fwd_kernel<true>, dim3(wgs), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv1x1_gate_fwd_kernel<false>, dim3(wgs), dim3(256), 0, s, a);
+  const bool bf = d->precision == LVAE_PREC_BF16;
+  if (wt && al) {
+    if (bf) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, true>), dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, false>), dim3(wgs), dim3(256), 0, s, a);
+  } else {
+    if (bf) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, true>), dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, false>), dim3(wgs), dim3(256), 0, s, a);
+  }
   LVAE_LAUNCH_CHECK("conv1x1_gate_fwd");
   return 0;
 }

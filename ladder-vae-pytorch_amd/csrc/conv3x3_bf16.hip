@@ -21,12 +21,10 @@
 // conv3x3_halo.hip.
 #include <string.h>
 
+#include "bf16_frag.h"
 #include "lvae_common.h"
 
 namespace lvae {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct BfArgs {
   lvae_conv_desc d;
@@ -475,8 +473,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16p_kernel(BfArgs a) {
 // its <= 5 accumulator tiles (32 ci x 32 co each) in registers across all tiles; the raw x / dy of the next tile are prefetched
 // into registers during the MFMAs. Per-workgroup partial slabs [workgroup][tap][ci][co] + [workgroup][co], fixed-order reduce.
 // ---------------------------------------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
 struct BfWgArgs {
   lvae_conv_desc d;
   const float* dy;
@@ -485,15 +481,6 @@ struct BfWgArgs {
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntiles, Cin, bm, split;
   uint32_t m_thw, m_tw, m_per_img, m_halo_w, m_tiles_h;
 };
-
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {
-  // two transposed 4 x 16 blocks -> the 8 consecutive k (pixels) of this lane's channel
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 // SPLIT = 1: bf16 operands. SPLIT = 3: both operands split exactly into three bf16 pieces and the six piece products of order <= 2^-16
 // accumulated (conv3x3_bf16_kernel's fp32-equivalent form). Unlike the forward kernel this one is bound by its slab traffic, not by

@@ -306,6 +306,31 @@ def test_conv1x1_gate_fused(K, shape):
     assert abn is None and rel(nchw(outn), out - res) < 2e-6
 
 
+@pytest.mark.parametrize('shape', [(40, 64, 16, 16), (129, 64, 16, 16), (37, 64, 3, 3)])
+def test_conv1x1_gate_fused_bf16_operands(K, shape):
+    """GateLayer2d forward at precision bf16: x and W rounded to bf16 at the matrix-core inputs, fp32 accumulate, fp32 gate / residual /
+    statistics. Against the fp64 result over operands rounded beforehand."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(12)
+    x, res = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w, b = torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C), torch.randn(2 * C, generator=g)
+    bf = lambda t_: t_.bfloat16().double()
+    ab = F.conv2d(bf(x), bf(w), b.double())
+    a_, b_ = ab.chunk(2, 1)
+    out = F.elu(a_) * torch.sigmoid(b_) + res.double()
+    wp = packed_weight(w)
+    pivot = torch.randn(C, generator=g).cuda()
+    K.set_precision('bf16')
+    try:
+        abd, outd, parts = K.conv1x1_gate(nhwc(x), wp, K.ConvGeom(wp, 1, 0), b.cuda(), nhwc(res), 'elu', stats_pivot=pivot)
+    finally:
+        K.set_precision('f32')
+    assert rel(nchw(abd), ab.float()) < 2e-6 and rel(nchw(outd), out.float()) < 2e-6
+    d = outd.reshape(-1, C).double() - pivot.double()
+    pr = parts.rows_view().double()
+    assert rel(pr[:, 0].sum(0), d.sum(0)) < 1e-5 and rel(pr[:, 1].sum(0), (d * d).sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (70, 32, 8, 8), (5, 8, 2, 2)])
 def test_conv1x1_gate_bwd_fused(K, shape):
     """gate backward + 1x1 dgrad in one kernel == lvae_gate_bwd_f32 followed by lvae_conv2d_f32 (and both == autograd)."""
@@ -712,6 +737,44 @@ def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape):
     # small layers are not taken (the caller composes gate_bwd + wgrad)
     small = K.conv1x1_gate_bwd_wgrad(nhwc(dout[:4]), nhwc(ab.detach()[:4]), nhwc(x.detach()[:4]), wp, geom, 'elu', dw, db) if H * W * 4 < 16384 else None
     assert small is None
+
+
+@pytest.mark.parametrize('shape', [(256, 16, 16), (67, 16, 16), (300, 8, 8), (19, 32, 32)])
+def test_conv1x1_gate_bwd_fused_bf16_operands(K, shape):
+    """The fused GateLayer2d backward at precision bf16: dab, the saved convolution input and W are rounded to bf16 at the matrix-core
+    inputs (fp32 accumulate), the gate derivative and the bias gradient stay fp32. Against fp64 sums over operands rounded beforehand."""
+    N, H, W = shape
+    C = 64
+    g = torch.Generator().manual_seed(N + H + 1)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(2 * C, C, 1, 1, generator=g) / math.sqrt(C)
+    b = torch.randn(2 * C, generator=g)
+    ab = F.conv2d(x, w, b)
+    a_, b_ = ab.double().chunk(2, 1)
+    dout = torch.randn(N, C, H, W, generator=g)
+    mask = (torch.rand(N, C, generator=g) < 0.8).float() / 0.8
+    sg = torch.sigmoid(b_)
+    dab = torch.cat([dout.double() * sg * torch.where(a_ > 0, torch.ones_like(a_), a_.exp()),
+                     dout.double() * F.elu(a_) * sg * (1 - sg)], 1)                       # fp64 gate derivative (lib/nn.py:118-126)
+    bf = lambda t_: t_.float().bfloat16().double()
+    w2 = bf(w[:, :, 0, 0])                                                                  # [2C][C]
+    dx_ref = torch.einsum('nkhw,kc->nchw', bf(dab), w2) * mask.view(N, C, 1, 1).double()
+    dw_ref = torch.einsum('nkhw,nchw->kc', bf(dab), bf(x))
+    db_ref = dab.sum((0, 2, 3))
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 0)
+    dw0, db0 = torch.randn(2 * C, C, 1, 1, generator=g) * 0.1, torch.randn(2 * C, generator=g)
+    dw, db = packed_weight(dw0), db0.cuda()
+    K.set_precision('bf16')
+    try:
+        dx = K.conv1x1_gate_bwd_wgrad(nhwc(dout), nhwc(ab), nhwc(x), wp, geom, 'elu', dw, db, out_scale=mask.cuda())
+    finally:
+        K.set_precision('f32')
+    assert dx is not None, "shape is meant to take the fused kernel"
+    # 3e-4: an operand that sits on a bf16 rounding boundary may round the other way on the GPU (fast exp in the gate derivative)
+    assert rel(nchw(dx), dx_ref.float()) < 3e-4
+    assert rel((dw.cpu() - dw0)[:, :, 0, 0], dw_ref.float()) < 3e-4
+    assert rel(db.cpu() - db0, db_ref.float()) < 5e-6
 
 
 @pytest.mark.parametrize('case', [(256, 64, 64, 16, 16), (33, 64, 64, 32, 32), (300, 64, 64, 8, 8), (70, 32, 64, 16, 16), (40, 64, 100, 32, 32)])
