@@ -363,6 +363,31 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
   __shared__ float cf[2][256];
   const int t = threadIdx.x, col = t % cols, rg = t / cols;
   const int c = col * 4;
+  // the first four rows of this thread are requested BEFORE the partial rows are summed: the two memory round trips overlap instead
+  // of following each other (these launches are latency chains: 8.2 us whether the level has 1,024 or 16,384 pixels)
+  constexpr int RP = 4;
+  const int stride = gridDim.x * rpp, row0 = blockIdx.x * rpp + rg;
+  F4 xv[RP], gv[RP], av[RP];
+  if (rg < rpp) {
+#pragma unroll
+    for (int u = 0; u < RP; ++u) {
+      const int row = row0 + u * stride;
+      const size_t off = (size_t)(row < M ? row : 0) * C + c;
+      xv[u] = Vec<4>::load(x + off);
+      gv[u] = Vec<4>::load(dh + off);
+      if (add) av[u] = Vec<4>::load(add + off);
+    }
+  }
+  // ... and so are the per-channel coefficients and workgroup 0's gradient accumulators
+  float sc[4], sh[4], mu[4], rs[4];
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = scale[c + j];
+    sh[j] = shift[c + j];
+    mu[j] = mean[c + j];
+    rs[j] = rstd[c + j];
+  }
+  const bool acc_here = blockIdx.x == 0 && t < C;
+  const float db0 = acc_here && dbeta ? dbeta[t] : 0.f, dg0 = acc_here && dgamma ? dgamma[t] : 0.f;
   {
     // slice rg of the partial rows for channel group col: rows rg, rg + nsl, ... (nsl = 256 / cols slices)
     const int nsl = 256 / cols;
@@ -397,38 +422,41 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
       cf[0][t] = (float)(sa / (double)M);
       cf[1][t] = (float)(sb / (double)M);
       if (blockIdx.x == 0) {
-        if (dbeta) dbeta[t] += (float)sa;
-        if (dgamma) dgamma[t] += (float)sb;
+        if (dbeta) dbeta[t] = db0 + (float)sa;
+        if (dgamma) dgamma[t] = dg0 + (float)sb;
       }
     }
     __syncthreads();
   }
   if (rg >= rpp) return;
-  float sc[4], sh[4], mu[4], rs[4], c1[4], c2[4];
+  float c1[4], c2[4];
   for (int j = 0; j < 4; ++j) {
-    sc[j] = scale[c + j];
-    sh[j] = shift[c + j];
-    mu[j] = mean[c + j];
-    rs[j] = rstd[c + j];
     c1[j] = cf[0][c + j];
     c2[j] = cf[1][c + j];
   }
-  for (int row = blockIdx.x * rpp + rg; row < M; row += gridDim.x * rpp) {
-    const size_t off = (size_t)row * C + c;
-    F4 xv = Vec<4>::load(x + off);
-    F4 gv = Vec<4>::load(dh + off);
-    F4 av;
-    if (add) av = Vec<4>::load(add + off);
+  auto apply = [&](int row, const F4& xq, F4 gq, const F4& aq) {
     const float* dr = drop ? drop + (size_t)(row / rows_per_n) * C + c : nullptr;
     for (int j = 0; j < 4; ++j) {
-      const float xx = xv.v[j];
-      float g = gv.v[j] * act_grad(xx * sc[j] + sh[j], act);
+      const float xx = xq.v[j];
+      float g = gq.v[j] * act_grad(xx * sc[j] + sh[j], act);
       g = (g - c1[j] - (xx - mu[j]) * rs[j] * c2[j]) * sc[j];
       if (dr) g *= dr[j];
-      if (add) g += av.v[j];
-      gv.v[j] = g;
+      if (add) g += aq.v[j];
+      gq.v[j] = g;
     }
-    Vec<4>::store(dx + off, gv);
+    Vec<4>::store(dx + (size_t)row * C + c, gq);
+  };
+#pragma unroll
+  for (int u = 0; u < RP; ++u) {
+    const int row = row0 + u * stride;
+    if (row < M) apply(row, xv[u], gv[u], av[u]);
+  }
+  for (int row = row0 + RP * stride; row < M; row += stride) {
+    const size_t off = (size_t)row * C + c;
+    const F4 xq = Vec<4>::load(x + off), gq = Vec<4>::load(dh + off);
+    F4 aq = xq;
+    if (add) aq = Vec<4>::load(add + off);
+    apply(row, xq, gq, aq);
   }
 }
 
