@@ -27,4 +27,19 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 lo, const f32x4 hi) {
   return bf16x8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
 }
 
+// v = out[0] + out[1] + ... exactly (SPLIT = 3: all 24 significant bits; SPLIT = 1: the round-to-nearest bf16 value)
+template <int SPLIT>
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) {
+      const __bf16 b = (__bf16)r;
+      out[p][j] = b;
+      if (p + 1 < SPLIT) r -= (float)b;  // exact: the remainder of a round-to-nearest to 8 bits has at most 16 significant bits
+    }
+  }
+}
+
 }  // namespace lvae

@@ -182,33 +182,44 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
   }
 }
 
-// The same kernel for precision = LVAE_PREC_BF16: dab, y and W are rounded to bf16 where they enter the matrix cores
-// (v_mfma_f32_32x32x16_bf16, fp32 accumulate); the gate derivative itself, the bias gradient and everything that leaves the kernel stay
-// fp32. The fp32 kernel's 15.8 us of MFMA time (which VALU work cannot hide under, see above) shrink to under 1 us on the bf16 unit,
-// which does run beside the vector ALU. dab / y tiles are [pixel][channel] bf16 images; the dgrad reads its A fragments row-wise
-// (ds_read_b128, W fragments in 32 registers per dgrad wave), the weight gradient needs 8 consecutive PIXELS of one channel per lane
-// for both operands and reads them with the transposing ds_read_b64_tr_b16 (bf16_frag.h), as conv3x3_wgrad_bf16_kernel does.
+// The same kernel on the bf16 matrix unit (v_mfma_f32_32x32x16_bf16, fp32 accumulate), which - unlike the fp32 MFMA - runs beside the
+// vector ALU. The gate derivative itself, the bias gradient and everything that leaves the kernel stay fp32.
+//   SPLIT = 1 (precision = LVAE_PREC_BF16): dab, y and W are rounded to bf16 where they enter the matrix cores.
+//   SPLIT = 3 (precision = LVAE_PREC_F32, the default fp32 form): each operand is split exactly into three bf16 pieces and the six piece
+//     products of order <= 2^-16 are accumulated (fp32-equivalent, the dropped terms are below 2^-24 of the product; same tolerances in
+//     the parity tests as the fp32 MFMA). Six bf16 MFMAs cost 6/16 of one fp32 MFMA and no longer add to the gate arithmetic:
+//     LVAE_GATE_BWD_F32_MFMA=1 goes back to conv1x1_gate_bwd_fused_kernel above.
+// dab / y tiles are [piece][pixel][channel] bf16 images; the dgrad reads its A fragments row-wise (ds_read_b128, W fragments in
+// registers of the dgrad waves), the weight gradient needs 8 consecutive PIXELS of one channel per lane for both operands and reads
+// them with the transposing ds_read_b64_tr_b16 (bf16_frag.h), as conv3x3_wgrad_bf16_kernel does.
 constexpr int GBB_LDA = 136;  // dab row pitch in bf16 (128 channels + 8: 272 bytes, 16-byte multiples for ds_read_b128)
 constexpr int GBB_LDY = 72;   // y row pitch in bf16
-constexpr size_t GBB_LDS = (size_t)64 * GBB_LDA * 2 + (size_t)64 * GBB_LDY * 2 + (size_t)64 * GB_LDY * 4;
+constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4; }
 
+template <int SPLIT>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [64 px][136]: dab tile
-  __bf16* Ys = As + 64 * GBB_LDA;                                    // [64 px][72]: y tile
-  float* Os = reinterpret_cast<float*>(Ys + 64 * GBB_LDY);           // [64 px][68]: dx staging (fp32)
+  constexpr int A_PLANE = 64 * GBB_LDA, Y_PLANE = 64 * GBB_LDY;
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [SPLIT][64 px][136]: dab tile
+  __bf16* Ys = As + SPLIT * A_PLANE;                                 // [SPLIT][64 px][72]: y tile
+  float* Os = reinterpret_cast<float*>(Ys + SPLIT * Y_PLANE);        // [64 px][68]: dx staging (fp32)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool wg_role = wave >= 4;  // waves 4-7: weight gradient; waves 0-3: dgrad
   const int wm = (wave & 3) >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5, G = lane >> 4, i16 = lane & 15;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s
-  bf16x8 breg[8];
+  // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s, SPLIT pieces
+  bf16x8 breg[8][SPLIT];
   if (!wg_role) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const float* wp = a.w + (int64_t)(wn * 32 + li) * a.w_sn + 16 * s + 8 * lh;
-      breg[s] = to_bf16x8(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4));
+      bf16x4 lo[SPLIT], hi[SPLIT];
+      split4<SPLIT>(*reinterpret_cast<const f32x4*>(wp), lo);
+      split4<SPLIT>(*reinterpret_cast<const f32x4*>(wp + 4), hi);
+#pragma unroll
+      for (int q = 0; q < SPLIT; ++q)
+        breg[s][q] = bf16x8{lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
     }
   }
 
@@ -236,6 +247,10 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
   f32x4 bs_lo = zero4, bs_hi = zero4;  // bias-gradient partials (fp32 dab, not the rounded operand)
   // transposed-read addresses of this lane (bf16_frag.h): pixel row 8 (G >> 1) + (i16 >> 2) of a k-step, channel 16 (G & 1) + 4 (i16 & 3) of a block
   const int trow = 8 * (G >> 1) + (i16 >> 2), tch = 16 * (G & 1) + 4 * (i16 & 3);
+  // piece products in ascending order of magnitude: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); SPLIT = 1: the single product
+  constexpr int NP = SPLIT == 1 ? 1 : 6;
+  constexpr int PA[6] = {SPLIT - 1, 0, SPLIT > 1 ? 1 : 0, SPLIT > 1 ? 1 : 0, 0, 0};
+  constexpr int PB[6] = {0, SPLIT - 1, SPLIT > 1 ? 1 : 0, 0, SPLIT > 1 ? 1 : 0, 0};
 
   int tile = blockIdx.x;
   if (tile < a.ntiles) prefetch(tile);
@@ -256,9 +271,16 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       }
       bs_lo += lo;
       bs_hi += hi;
-      *reinterpret_cast<bf16x4*>(As + r * GBB_LDA + c4) = to_bf16x4(lo);
-      *reinterpret_cast<bf16x4*>(As + r * GBB_LDA + 64 + c4) = to_bf16x4(hi);
-      *reinterpret_cast<bf16x4*>(Ys + r * GBB_LDY + c4) = to_bf16x4(yv);
+      bf16x4 pl[SPLIT], ph[SPLIT], pyv[SPLIT];
+      split4<SPLIT>(lo, pl);
+      split4<SPLIT>(hi, ph);
+      split4<SPLIT>(yv, pyv);
+#pragma unroll
+      for (int q = 0; q < SPLIT; ++q) {
+        *reinterpret_cast<bf16x4*>(As + q * A_PLANE + r * GBB_LDA + c4) = pl[q];
+        *reinterpret_cast<bf16x4*>(As + q * A_PLANE + r * GBB_LDA + 64 + c4) = ph[q];
+        *reinterpret_cast<bf16x4*>(Ys + q * Y_PLANE + r * GBB_LDY + c4) = pyv[q];
+      }
     }
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
@@ -270,8 +292,12 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       for (int r = 0; r < 16; ++r) accx[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + li) * GBB_LDA + 16 * s + 8 * lh);
-        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, breg[s], accx, 0, 0, 0);
+        bf16x8 af[SPLIT];
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q)
+          af[q] = *reinterpret_cast<const bf16x8*>(As + q * A_PLANE + (wm * 32 + li) * GBB_LDA + 16 * s + 8 * lh);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], breg[s][PB[k]], accx, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
@@ -279,13 +305,22 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       // ---- weight gradient: dW[32 ci (wn)][2 x 32 co (wm)] += y^T . dab, k = pixel: 4 k-steps of 16 pixels
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const __bf16* yp = Ys + (16 * s + trow) * GBB_LDY + wn * 32 + tch;
-        const bf16x8 af = tr_frag(yp, yp + 4 * GBB_LDY);
+        bf16x8 af[SPLIT];
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) {
+          const __bf16* yp = Ys + q * Y_PLANE + (16 * s + trow) * GBB_LDY + wn * 32 + tch;
+          af[q] = tr_frag(yp, yp + 4 * GBB_LDY);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const __bf16* dp = As + (16 * s + trow) * GBB_LDA + (wm * 2 + j) * 32 + tch;
-          const bf16x8 bf = tr_frag(dp, dp + 4 * GBB_LDA);
-          accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accw[j], 0, 0, 0);
+          bf16x8 bf[SPLIT];
+#pragma unroll
+          for (int q = 0; q < SPLIT; ++q) {
+            const __bf16* dp = As + q * A_PLANE + (16 * s + trow) * GBB_LDA + (wm * 2 + j) * 32 + tch;
+            bf[q] = tr_frag(dp, dp + 4 * GBB_LDA);
+          }
+#pragma unroll
+          for (int k = 0; k < NP; ++k) accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bf[PB[k]], accw[j], 0, 0, 0);
         }
       }
     }
@@ -375,8 +410,25 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     }
     attr_set = true;
   }
-  if (d->precision == LVAE_PREC_BF16) hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel, dim3(nwg), dim3(512), GBB_LDS, s, a);
-  else hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
+  const char* f32sw = getenv("LVAE_GATE_BWD_F32_MFMA");  // A/B switch, read per call (the parity tests run both fp32 forms in one process)
+  const bool f32_mfma = f32sw != nullptr && atoi(f32sw) != 0;
+  if (d->precision == LVAE_PREC_BF16) {
+    hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel<1>, dim3(nwg), dim3(512), gbb_lds(1), s, a);
+  } else if (!f32_mfma) {
+    static std::atomic<bool> attr3_set{false};
+    if (!attr3_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
+      if (e != hipSuccess) {
+        set_error("conv1x1_gate_bwd_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return (int)e;
+      }
+      attr3_set = true;
+    }
+    hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel<3>, dim3(nwg), dim3(512), gbb_lds(3), s, a);
+  } else {
+    hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
+  }
   LVAE_LAUNCH_CHECK("conv1x1_gate_bwd_fused");
   // slabs are [nwg][ci][co]: the gate convolution's weight element (ci, co) lives at dw[ci * dw_sk + co * dw_sn]
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 1, 64, 128, 0, dw_sk, dw_sn, dw, db, s);

@@ -40,13 +40,22 @@ constexpr int GF_LDO = 40;  // staging row stride (floats): 4 rows = 160 = 32 mo
 // WT: the three outputs leave as 16-byte write-through stores (store_wt4), transposed from the accumulator layout through a 5 KB LDS
 // strip that belongs to the wave alone (no workgroup barrier: a wave's LDS instructions execute in order); the residual rows are
 // then fetched as float4 in the store layout. !WT: one dword per lane straight from the accumulators, plain stores.
-// BF16 (precision = LVAE_PREC_BF16): x and W are rounded to bf16 where they enter the matrix cores (v_mfma_f32_32x32x16_bf16, fp32
-// accumulate): 8 MFMAs per wave and tile instead of 64, on a unit that runs beside the vector ALU; everything after the accumulators is
-// the fp32 code. The x tile is a [pixel][channel] bf16 image (pitch 72) in the same LDS buffers.
+// SPLIT: 0 = v_mfma_f32_32x32x2_f32. 1 (precision = LVAE_PREC_BF16) = x and W rounded to bf16 where they enter the matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate): 8 MFMAs per wave and tile instead of 64, on a unit that - unlike the fp32 MFMA - runs
+// beside the vector ALU. 3 (LVAE_GATE_FWD_F32_SPLIT=1, for precision = LVAE_PREC_F32) = both operands split exactly into three bf16 pieces,
+// the six piece products of order <= 2^-16 accumulated: fp32-equivalent (same parity tolerances), 6/16 of the fp32 matrix time and off
+// the vector ALU's lanes. The fused backward kernel gains 0.34 ms per step from this form; this kernel is bound by its HBM traffic, not by
+// its 7 us of fp32 MFMA, and measured 36.97 ms per step with it against 36.86 ms without, so SPLIT = 0 stays the fp32 default (the
+// parity tests run both). Everything after the accumulators is the same fp32 code. The x
+// tile is a [piece][pixel][channel] bf16 image (pitch 72) in the LDS buffers.
 constexpr int GF_LDB = 72;
-template <bool WT, bool BF16>
+constexpr int GF_PLANE = GF_BM * GF_LDB;  // bf16 elements per piece
+template <bool WT, int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[2][GF_BM * GF_LDA];
+  constexpr bool BF16 = SPLIT > 0;
+  constexpr int NPIECE = SPLIT > 0 ? SPLIT : 1;
+  constexpr int A_FLOATS = SPLIT > 1 ? SPLIT * GF_PLANE / 2 : GF_BM * GF_LDA;  // floats per x buffer (SPLIT <= 1: the fp32 tile covers both)
+  __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
   __shared__ __attribute__((aligned(16))) float Os[WT ? 4 : 1][WT ? 32 * GF_LDO : 4];
   __shared__ __attribute__((aligned(16))) float red[2][2][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -68,8 +77,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
-      if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + r * GF_LDB + k) = to_bf16x4(av[u]);
-      else *reinterpret_cast<f32x4*>(dst + r * GF_LDA + k) = av[u];
+      if (BF16) {
+        bf16x4 pl[NPIECE];
+        split4<NPIECE>(av[u], pl);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + q * GF_PLANE + r * GF_LDB + k) = pl[q];
+      } else {
+        *reinterpret_cast<f32x4*>(dst + r * GF_LDA + k) = av[u];
+      }
     }
   };
 
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
   // B operands: k-step s = 4 g + j of group g multiplies A[.][8 g + 4 lh + j] (the four floats of this lane's ds_read_b128)
   // (BF16: k-step s of 16 multiplies A[.][16 s + 8 lh + 0..7], the eight bf16 of this lane's ds_read_b128)
   float breg[2][BF16 ? 1 : 32];
-  bf16x8 bq[2][BF16 ? 4 : 1];
+  bf16x8 bq[2][BF16 ? 4 : 1][NPIECE];
   if (BF16) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -87,7 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
         float wv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) wv[j] = a.w[(int64_t)(16 * s + 8 * lh + j) * a.w_sk + (int64_t)(ni * 64 + ch) * a.w_sn];
-        bq[ni][s] = to_bf16x8(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+        bf16x4 lo[NPIECE], hi[NPIECE];
+        split4<NPIECE>(f32x4{wv[0], wv[1], wv[2], wv[3]}, lo);
+        split4<NPIECE>(f32x4{wv[4], wv[5], wv[6], wv[7]}, hi);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q)
+          bq[ni][s][q] = bf16x8{lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
       }
   } else {
 #pragma unroll
@@ -138,12 +158,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
     if (BF16) {
+      // piece products in ascending order of magnitude: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); one piece: the single product
+      constexpr int NP = NPIECE == 1 ? 1 : 6;
+      constexpr int PA[6] = {NPIECE - 1, 0, NPIECE > 1 ? 1 : 0, NPIECE > 1 ? 1 : 0, 0, 0};
+      constexpr int PB[6] = {0, NPIECE - 1, NPIECE > 1 ? 1 : 0, 0, NPIECE > 1 ? 1 : 0, 0};
       const __bf16* arow = reinterpret_cast<const __bf16*>(As[cur]) + (wm * 32 + li) * GF_LDB + 8 * lh;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[1][s], acc1, 0, 0, 0);
+        bf16x8 af[NPIECE];
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) af[q] = *reinterpret_cast<const bf16x8*>(arow + q * GF_PLANE + 16 * s);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bq[0][s][PB[k]], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bq[1][s][PB[k]], acc1, 0, 0, 0);
+        }
       }
     } else {
       const float* arow = As[cur] + (wm * 32 + li) * GF_LDA + 4 * lh;
@@ -285,13 +314,17 @@ int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, 
   static const bool wt = getenv("LVAE_GATE_FWD_WT") == nullptr || atoi(getenv("LVAE_GATE_FWD_WT")) != 0;  // A/B switch, profiling only
   const bool al = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d->y) |
                     reinterpret_cast<uintptr_t>(d->stats_pivot)) & 15) == 0;
-  const bool bf = d->precision == LVAE_PREC_BF16;
+  const char* f32sw = getenv("LVAE_GATE_FWD_F32_SPLIT");  // A/B switch, read per call (the parity tests run both fp32 forms in one process)
+  const int split = d->precision == LVAE_PREC_BF16 ? 1 : ((f32sw != nullptr && atoi(f32sw) != 0) ? 3 : 0);
+  const dim3 grid(wgs), block(256);
   if (wt && al) {
-    if (bf) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, true>), dim3(wgs), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, false>), dim3(wgs), dim3(256), 0, s, a);
+    if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1>), grid, block, 0, s, a);
+    else if (split == 3) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 0>), grid, block, 0, s, a);
   } else {
-    if (bf) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, true>), dim3(wgs), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, false>), dim3(wgs), dim3(256), 0, s, a);
+    if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, 1>), grid, block, 0, s, a);
+    else if (split == 3) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, 3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<false, 0>), grid, block, 0, s, a);
   }
   LVAE_LAUNCH_CHECK("conv1x1_gate_fwd");
   return 0;

@@ -38,20 +38,6 @@ struct BfArgs {
 constexpr int kBfNotEligible = -1000;
 constexpr int BF_LDK = 72;   // bf16 elements per LDS row (64 channels + 8 pad = 144 bytes)
 
-template <int SPLIT>
-__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float r = v[j];
-#pragma unroll
-    for (int p = 0; p < SPLIT; ++p) {
-      const __bf16 b = (__bf16)r;
-      out[p][j] = b;
-      if (p + 1 < SPLIT) r -= (float)b;  // exact: the remainder of a round-to-nearest to 8 bits has at most 16 significant bits
-    }
-  }
-}
-
 // MI: 32-pixel MFMA row blocks per wave; the workgroup tile is BM = 64 * MI output pixels x 64 output channels, 4 waves 2(M) x 2(N)
 // PRE (SPLIT == 1 only): the wave's whole B slice is fetched up front (144 registers, two workgroups per CU) — for layers whose grid is a
 // single round of workgroups, where the per-tile latency chain is the launch time; larger grids keep the three-deep ring (87 registers,

@@ -287,10 +287,14 @@ def test_bn_stats_and_affine_bwd(K, shape):
     assert rel(dg.cpu(), gamma.grad) < 1e-5 and rel(db.cpu(), beta.grad) < 1e-5
 
 
+@pytest.mark.parametrize('form', ['split', 'mfma_f32'])
 @pytest.mark.parametrize('shape', [(40, 64, 16, 16), (3, 64, 4, 4), (2, 8, 2, 2), (70, 32, 8, 8),
                                    (129, 64, 16, 16),   # persistent kernel: 516 tiles over 512 workgroups (four of them take two)
                                    (37, 64, 3, 3)])     # ... ragged last tile
-def test_conv1x1_gate_fused(K, shape):
+def test_conv1x1_gate_fused(K, shape, form, monkeypatch):
+    """GateLayer2d forward fused with its 1x1 convolution; both fp32 forms of the persistent kernel (six exact bf16-piece products per
+    fp32 product on the bf16 MFMA, LVAE_GATE_FWD_F32_SPLIT=1, and the fp32 MFMA, the default)."""
+    monkeypatch.setenv('LVAE_GATE_FWD_F32_SPLIT', '0' if form == 'mfma_f32' else '1')
     N, C, H, W = shape
     g = torch.Generator().manual_seed(11)
     x, res = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
@@ -709,10 +713,13 @@ def test_conv3x3_bf16_operands(K, case):
         assert rel(nchw(dx), dref) < 1e-5
 
 
+@pytest.mark.parametrize('form', ['split', 'mfma_f32'])
 @pytest.mark.parametrize('shape', [(256, 16, 16), (70, 16, 16), (33, 32, 32), (257, 8, 8)])
-def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape):
+def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape, form, monkeypatch):
     """lvae_conv1x1_gate_bwd_wgrad_f32 (gate derivative + dgrad + weight / bias gradient of the gate convolution, one persistent
-    kernel) == autograd of lib/nn.py:118-126, accumulating into non-zero gradient buffers."""
+    kernel) == autograd of lib/nn.py:118-126, accumulating into non-zero gradient buffers. Both fp32 forms: six exact bf16-piece
+    products per fp32 product on the bf16 MFMA (default) and the fp32 MFMA (LVAE_GATE_BWD_F32_MFMA=1)."""
+    monkeypatch.setenv('LVAE_GATE_BWD_F32_MFMA', '1' if form == 'mfma_f32' else '0')
     N, H, W = shape
     C = 64
     g = torch.Generator().manual_seed(N + H)
