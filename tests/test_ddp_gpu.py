@@ -51,7 +51,10 @@ def _max_rel(a, b):
     return worst
 
 
-def test_two_shard_mean_gradient_matches_oracle_per_shard():
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_two_shard_mean_gradient_matches_oracle_per_shard(dtype):
+    """bf16: BASELINE configs[3]'s arithmetic (bf16 matrix-core operands, fp32 accumulate / statistics / KL / likelihood) under the same
+    data-parallel semantics, against the fp32 oracle at north_star's bf16 tolerance (ELBO 1e-2 relative; gradients looser still)."""
     import lvae_amd  # noqa: F401
     from lvae_amd.engine import forward_pass
     from lvae_amd.models.lvae import LadderVAE
@@ -83,13 +86,15 @@ def test_two_shard_mean_gradient_matches_oracle_per_shard():
     # HIP engine: the same model object sees the two shards one after the other; flat gradient arenas are summed and halved,
     # exactly what the all-reduce + the optimiser's 1/world scale do
     model.cuda().train()
+    model.compute_dtype = dtype
+    loss_tol, grad_tol, norm_tol = (1e-5, 1e-4, 1e-6) if dtype == 'f32' else (1e-2, 5e-2, 1e-2)
     arena = model.pack()
     flat = torch.zeros_like(arena.grads)
     for r, xs in enumerate(shards):
         model.noise = TapeNoise(tapes[r])
         arena.zero_grad()
         out = forward_pass(model, xs.cuda())
-        assert abs(float(out['loss']) - ref_loss[r]) <= 1e-5 * abs(ref_loss[r])
+        assert abs(float(out['loss']) - ref_loss[r]) <= loss_tol * abs(ref_loss[r])
         out['loss'].backward()
         flat += arena.grads
     arena.grads.copy_(flat * 0.5)
@@ -102,8 +107,8 @@ def test_two_shard_mean_gradient_matches_oracle_per_shard():
         if float(ref.norm()) < 1e-5 * max(1.0, ref.numel() ** 0.5):
             continue
         worst = max(worst, float((g - ref).norm() / ref.norm()))
-    assert worst < 1e-4, worst
-    assert abs(gsq ** 0.5 - rsq ** 0.5) <= 1e-6 * rsq ** 0.5
+    assert worst < grad_tol, worst
+    assert abs(gsq ** 0.5 - rsq ** 0.5) <= norm_tol * rsq ** 0.5
 
 
 def test_forced_rccl_rank_overlapped_graph_step_matches_single_rank(tmp_path):
