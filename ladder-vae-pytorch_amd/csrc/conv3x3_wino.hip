@@ -120,14 +120,23 @@ constexpr int WLDO = 68;  // R row stride (floats)
 // for layers with fewer than 256 pixel tiles (the 8x8 level at batch 256): it fills all CUs, halves the dependent MFMA chain
 // of a wave, and — one wave per SIMD, nothing else to hide an L2 round trip — keeps its U fragments three k-steps ahead in a
 // register ring pinned with sched_barrier.
-template <int CIN, int NH>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+// MT: 32-tile row blocks per wave. 1 = the layout described above (128 output pixels per workgroup, two workgroups per CU).
+// 2 (LVAE_WINO_WIDE=1, an experiment that is parity-tested but NOT the default) = 256 output pixels per workgroup, ONE workgroup per CU,
+// one wave per SIMD with the whole 512-entry register file (sixteen 32x32 accumulators per wave, in AGPRs): every U fragment a wave
+// fetches from L2 feeds two MFMAs instead of one (the U stream is 262 KB per workgroup whatever its tile) and a 16x16 level at batch
+// 256 is exactly one image per CU. Measured: 46.2 us against 33.6 us at 256x16x16, 165 against 122 us at 32x32 (step 40.3 vs 37.1 ms).
+// With one wave per SIMD nothing covers a wave's LDS round trips, the slice barriers or the prologue / epilogue of the only resident
+// workgroup, and re-reading U was not what held the two-workgroup form back (reading every k-step's fragments from one hot 8 KB
+// changed its time by 1 %).
+template <int CIN, int NH, int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
   constexpr int WLDA = CIN + 4;     // halo pixel stride (floats)
   constexpr int KSTEPS = CIN / 8, NSLICE = CIN / 16;
   constexpr int CW = 32 * NH;       // output channels of this workgroup
   constexpr int C4N = CW / 4;       // float4 per output pixel
   constexpr int PG = 256 / C4N;     // pixel groups of the store pass
-  constexpr int QN = 128 / PG;      // store passes
+  constexpr int NT = 32 * MT;       // Winograd tiles of this workgroup
+  constexpr int QN = 4 * NT / PG;   // store passes
   constexpr int RING = NH == 1 ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;  // [halo_px][WLDA]; reused as R[4][2][32][WLDO] by the epilogue
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- halo patch in four 16-channel slices; slot = (pixel, float4 within the slice)
-  constexpr int SLOTS = 4;  // per thread and slice: halo_px <= 256 (checked by the launcher)
+  constexpr int SLOTS = MT == 1 ? 4 : 6;  // per thread and slice: halo_px <= 64 * SLOTS (checked by the launcher)
   const int per_img = a.halo_h * a.halo_w;
   const int hc4 = (t & 3) * 4;
   unsigned hoff[SLOTS];   // global offset (floats) of the pixel, or ~0u when it is padding
@@ -193,17 +202,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   load_slice(0);
 
   // ---- this lane's Winograd tile -> top-left halo pixel; this wave's two pixel rows of the 4x4 block
-  int wt = li;
-  if (wt >= a.n_wt) wt = 0;  // unused tile slots compute on a valid address; their results are never stored
-  const int wimg = fastdiv(wt, a.m_wt_per_img), wr = wt - wimg * a.wt_per_img;
-  const int wty = fastdiv(wr, a.m_tiles_x), wtx = wr - wty * a.tiles_x;
   // B^T rows: [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1]  ->  t = d[ra] + sgn * d[rb]
   const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
   const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float sgn = wave == 1 ? 1.f : -1.f;
-  const int pbase = (wimg * a.halo_h + 2 * wty) * a.halo_w + 2 * wtx;
-  const float* pa = As + (size_t)(pbase + ra * a.halo_w) * WLDA + 4 * lh;
-  const float* pb = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 4 * lh;
+  const float* pa[MT];
+  const float* pb[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int wt = li + 32 * m;
+    if (wt >= a.n_wt) wt = 0;  // unused tile slots compute on a valid address; their results are never stored
+    const int wimg = fastdiv(wt, a.m_wt_per_img), wr = wt - wimg * a.wt_per_img;
+    const int wty = fastdiv(wr, a.m_tiles_x), wtx = wr - wty * a.tiles_x;
+    const int pbase = (wimg * a.halo_h + 2 * wty) * a.halo_w + 2 * wtx;
+    pa[m] = As + (size_t)(pbase + ra * a.halo_w) * WLDA + 4 * lh;
+    pb[m] = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 4 * lh;
+  }
 
   // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
   const size_t slab = (size_t)a.Npad * CIN;
@@ -219,13 +233,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
   for (int q = 0; q < RING - 1; ++q) load_u(q, q);
 
-  f32x16 acc[4][NH];
+  f32x16 acc[MT][4][NH];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.f;
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][j][h][r] = 0.f;
 
   store_slice(0);
   load_slice(1);
@@ -234,26 +250,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   for (int ks = 0; ks < KSTEPS; ++ks) {
     if (ks + RING - 1 < KSTEPS) load_u(ks + RING - 1, (ks + RING - 1) % RING);
     if (NH == 1) __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead: the scheduler otherwise sinks it next to its use
-    f32x4 tt[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 da = *reinterpret_cast<const f32x4*>(pa + c * WLDA + ks * 8);
-      const f32x4 db = *reinterpret_cast<const f32x4*>(pb + c * WLDA + ks * 8);
+    for (int m = 0; m < MT; ++m) {
+      f32x4 tt[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tt[c][e] = __builtin_fmaf(sgn, db[e], da[e]);  // sgn = +-1: exact
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(pa[m] + c * WLDA + ks * 8);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(pb[m] + c * WLDA + ks * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tt[c][e] = __builtin_fmaf(sgn, db[e], da[e]);  // sgn = +-1: exact
+      }
+      f32x4 vv[4];
+      vv[0] = tt[0] - tt[2];
+      vv[1] = tt[1] + tt[2];
+      vv[2] = tt[2] - tt[1];
+      vv[3] = tt[1] - tt[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[m][j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks % RING][j][h][e], acc[m][j][h], 0, 0, 0);
     }
-    f32x4 vv[4];
-    vv[0] = tt[0] - tt[2];
-    vv[1] = tt[1] + tt[2];
-    vv[2] = tt[2] - tt[1];
-    vv[3] = tt[1] - tt[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks % RING][j][h][e], acc[j][h], 0, 0, 0);
     if (NH == 1) __builtin_amdgcn_sched_barrier(0);
     if ((ks & 1) && ks < KSTEPS - 1) {  // publish the next 16-channel slice, start fetching the one after
       const int c = (ks + 1) >> 1;
@@ -265,18 +284,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   __syncthreads();  // every wave is done with the halo patch: LDS becomes R[wave][b][tile][co]
 
   // ---- R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]; accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh
-  float* Rs = smem;
+  float* Rs = smem;  // R[wave i][b][NT tiles][WLDO]
 #pragma unroll
-  for (int h = 0; h < NH; ++h)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float r0 = acc[0][h][r] + acc[1][h][r] + acc[2][h][r];
-      const float r1 = acc[1][h][r] - acc[2][h][r] - acc[3][h][r];
-      float* o = Rs + (size_t)((wave * 2) * 32 + tile) * WLDO + h * 32 + li;
-      o[0] = r0;
-      o[32 * WLDO] = r1;
-    }
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tile = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float r0 = acc[m][0][h][r] + acc[m][1][h][r] + acc[m][2][h][r];
+        const float r1 = acc[m][1][h][r] - acc[m][2][h][r] - acc[m][3][h][r];
+        float* o = Rs + (size_t)((wave * 2) * NT + tile) * WLDO + h * 32 + li;
+        o[0] = r0;
+        o[NT * WLDO] = r1;
+      }
   __syncthreads();
   {
     const int c4 = (t % C4N) * 4, col = co0 + c4;
@@ -301,11 +322,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           const int img = fastdiv(p, a.m_thw), pr = p - img * thw;
           const int oy = fastdiv(pr, a.m_tw), ox = pr - oy * a.TW;
           const int tile = img * a.wt_per_img + (oy >> 1) * a.tiles_x + (ox >> 1);
-          const float* rp = Rs + (size_t)((ox & 1) * 32 + tile) * WLDO + c4;  // R[i][b = ox&1][tile]
+          const float* rp = Rs + (size_t)((ox & 1) * NT + tile) * WLDO + c4;  // R[i][b = ox&1][tile]
           const f32x4 R0 = *reinterpret_cast<const f32x4*>(rp);
-          const f32x4 R1 = *reinterpret_cast<const f32x4*>(rp + 64 * WLDO);
-          const f32x4 R2 = *reinterpret_cast<const f32x4*>(rp + 128 * WLDO);
-          const f32x4 R3 = *reinterpret_cast<const f32x4*>(rp + 192 * WLDO);
+          const f32x4 R1 = *reinterpret_cast<const f32x4*>(rp + 2 * NT * WLDO);
+          const f32x4 R2 = *reinterpret_cast<const f32x4*>(rp + 4 * NT * WLDO);
+          const f32x4 R3 = *reinterpret_cast<const f32x4*>(rp + 6 * NT * WLDO);
           f32x4 v = (oy & 1) ? (R1 - R2 - R3) : (R0 + R1 + R2);
           v = v + bias;
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
@@ -369,19 +390,47 @@ bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
   return true;
 }
 
+// Pixel tile of a workgroup: whole rows, even height, <= 128 * mt pixels (32 * mt Winograd tiles); whole images when several fit.
+// mt = 2 (256 pixels, one workgroup per CU, conv3x3_wino_kernel<64, 2, 2>) only with LVAE_WINO_WIDE=1, when the layer reduces over
+// <= 64 channels and such a grid still has at least 256 workgroups; otherwise mt = 1.
+struct WinoTile {
+  int TH, NI, mt;
+};
+
+static bool wino_tile_for(const lvae_conv_desc* d, int budget, int max_halo, int& TH, int& NI) {
+  TH = 0;
+  for (int c = 2; c <= d->H; c += 2)
+    if (d->H % c == 0 && c * d->W <= budget) TH = c;
+  if (TH == 0) return false;
+  NI = TH < d->H ? 1 : budget / (TH * d->W);
+  if (NI < 1) NI = 1;
+  if (NI > d->N) NI = d->N;
+  return NI * (TH + 2) * (d->W + 2) <= max_halo;
+}
+
+static bool wino_tile(const lvae_conv_desc* d, WinoTile& w) {
+  const char* wsw = getenv("LVAE_WINO_WIDE");  // experiment switch, read per call (the parity tests run both forms in one process)
+  const bool wide_on = wsw != nullptr && atoi(wsw) != 0;
+  int TH, NI;
+  if (wide_on && kpad_is64(d) && wino_tile_for(d, 256, 384, TH, NI)) {
+    const int64_t groups = (int64_t)((d->N + NI - 1) / NI) * (d->H / TH) * ((d->Cout + 63) / 64);
+    if (groups >= 256) {
+      w = WinoTile{TH, NI, 2};
+      return true;
+    }
+  }
+  if (!wino_tile_for(d, 128, 256, TH, NI)) return false;
+  w = WinoTile{TH, NI, 1};
+  return true;
+}
+
 // rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
 int conv3x3_wino_stats_rows(const lvae_conv_desc* d) {
   if (d->workspace == nullptr || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
-  int TH = 0;
-  for (int c = 2; c <= d->H; c += 2)
-    if (d->H % c == 0 && c * d->W <= 128) TH = c;
-  if (TH == 0) return 0;
-  int NI = TH < d->H ? 1 : 128 / (TH * d->W);
-  if (NI < 1) NI = 1;
-  if (NI > d->N) NI = d->N;
-  if (NI * (TH + 2) * (d->W + 2) > 256) return 0;
-  if ((size_t)NI * (TH + 2) * (d->W + 2) * ((d->C1 <= 64 ? 64 : 128) + 4) * sizeof(float) > 160 * 1024) return 0;
-  return ((d->N + NI - 1) / NI) * (d->H / TH);
+  WinoTile w;
+  if (!wino_tile(d, w)) return 0;
+  if ((size_t)w.NI * (w.TH + 2) * (d->W + 2) * ((d->C1 <= 64 ? 64 : 128) + 4) * sizeof(float) > 160 * 1024) return 0;
+  return ((d->N + w.NI - 1) / w.NI) * (d->H / w.TH);
 }
 
 // -1000: not eligible. `workspace` must hold conv3x3_wino_workspace(d) bytes (the transformed weights).
@@ -391,14 +440,9 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   const int Cin = d->C1;
   WinoArgs a;
   a.d = *d;
-  // tile: whole rows, even height, <= 128 pixels (32 Winograd tiles); whole images when several fit
-  int TH = 0;
-  for (int c = 2; c <= d->H; c += 2)
-    if (d->H % c == 0 && c * d->W <= 128) TH = c;
-  if (TH == 0) return -1000;
-  int NI = TH < d->H ? 1 : 128 / (TH * d->W);
-  if (NI < 1) NI = 1;
-  if (NI > d->N) NI = d->N;
+  WinoTile wtile;
+  if (!wino_tile(d, wtile)) return -1000;
+  const int TH = wtile.TH, NI = wtile.NI, mt = wtile.mt;
   a.TH = TH;
   a.TW = d->W;
   a.NI = NI;
@@ -406,14 +450,13 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.halo_h = TH + 2;
   a.halo_w = d->W + 2;
   a.halo_px = NI * a.halo_h * a.halo_w;
-  if (a.halo_px > 256) return -1000;
   a.tiles_x = d->W / 2;
   a.wt_per_img = (TH / 2) * a.tiles_x;
   a.n_wt = NI * a.wt_per_img;
   a.Npad = (d->Cout + 63) / 64 * 64;
   const int img_groups_ = (d->N + NI - 1) / NI;
   static const int narrow_tiles = getenv("LVAE_WINO_NARROW_TILES") ? atoi(getenv("LVAE_WINO_NARROW_TILES")) : 256;  // tuning switch
-  const bool narrow = kpad_is64(d) && img_groups_ * a.tiles_h < narrow_tiles;  // fewer pixel tiles than CUs: 32-channel workgroups
+  const bool narrow = mt == 1 && kpad_is64(d) && img_groups_ * a.tiles_h < narrow_tiles;  // fewer pixel tiles than CUs: 32-channel workgroups
   a.ntn = narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64;
   a.m_thw = fastdiv_magic(TH * d->W);
   a.m_tw = fastdiv_magic(d->W);
@@ -424,14 +467,15 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   const int kpad = wino_kpad(d);
   a.Cin = Cin;
   size_t lds = (size_t)a.halo_px * (kpad + 4) * sizeof(float);
-  const size_t lds_r = (size_t)4 * 2 * 32 * WLDO * sizeof(float);
+  const size_t lds_r = (size_t)4 * 2 * 32 * mt * WLDO * sizeof(float);
   if (lds < lds_r) lds = lds_r;
   if (lds > 160 * 1024) return -1000;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -448,9 +492,10 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1>), grid, dim3(256), lds, s, a);
-  else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2>), grid, dim3(256), lds, s, a);
+  if (mt == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 2>), grid, dim3(256), lds, s, a);
+  else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1>), grid, dim3(256), lds, s, a);
+  else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2, 1>), grid, dim3(256), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wino");
   return 0;
 }

@@ -105,6 +105,10 @@ WINO_CASES = [
     (64, 64, 16, 16),    # fewer than 256 pixel tiles: the 32-channel-per-workgroup variant with the pinned weight ring
     (257, 100, 8, 8),    # ... ragged last channel block, two images per tile, ragged last tile
     (300, 32, 8, 8),     # ... a single channel block
+    (257, 64, 16, 16),   # LVAE_WINO_WIDE=1, >= 256 pixel tiles of 256 pixels: one workgroup per CU, 512 registers per wave (MT = 2); ragged batch
+    (65, 64, 32, 32),    # ... 8-row tiles of a 32-wide image
+    (130, 100, 16, 16),  # ... two output-channel tiles, the second ragged
+    (300, 32, 24, 16),   # ... 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
 ]
 
 
@@ -116,6 +120,7 @@ def test_conv3x3_winograd(K, case, form, monkeypatch):
     ulp of fp32, including the fused BN/activation prologue and dropout/activation epilogue."""
     monkeypatch.setenv('LVAE_F32_SPLIT', '0' if form == 'winograd' else '1')
     monkeypatch.setenv('LVAE_F32_SPLIT_WGRAD', '0' if form == 'winograd' else '1')   # weight gradient: fp32 MFMA / six-product bf16 form
+    monkeypatch.setenv('LVAE_WINO_WIDE', '1' if case[0] in (257, 65, 130) or case == (300, 32, 24, 16) else '0')   # 256-pixel workgroups (MT = 2)
     N, Co, H, W = case
     C = 64
     g = torch.Generator().manual_seed(sum(case))
@@ -371,7 +376,7 @@ def test_colsum(K, shape):
     torch.testing.assert_close(out.cpu(), x.sum(0), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 32, 64, 8, 8), (9, 64, 100, 32, 32),
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 32, 64, 8, 8), (9, 64, 100, 32, 32), (258, 64, 64, 16, 16),
                                   (66, 64, 64, 16, 16), (259, 64, 100, 8, 8)])   # last two: 32-channel Winograd workgroups
 def test_bn_statistics_from_conv_epilogue(K, case):
     """conv2d(..., stats_pivot) + bn_finalize_parts == conv2d followed by bn_stats on its output (Winograd and tile kernels)."""
@@ -419,7 +424,7 @@ def test_bn_statistics_from_gate_epilogue(K, shape):
     torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 64, 32, 8, 8), (66, 64, 64, 16, 16), (259, 64, 64, 8, 8)])
+@pytest.mark.parametrize('case', [(200, 64, 64, 16, 16), (37, 64, 64, 4, 4), (70, 64, 32, 8, 8), (66, 64, 64, 16, 16), (259, 64, 64, 8, 8), (258, 64, 64, 16, 16)])
 def test_bn_backward_sums_from_dgrad_epilogue(K, case):
     """conv2d_dgrad(..., bn_bwd) + affine_act_bwd_parts == conv2d_dgrad followed by affine_act_bwd (Winograd and tile kernels)."""
     N, Ci, Co, H, W = case
