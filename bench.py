@@ -286,7 +286,7 @@ def main():
         if args.dtype == 'f32':
             issued = 16.0 / 36.0 if is_wino else 1.0
             traffic, traffic_src = pmc_traffic(dkey, is_wino)
-            kname = 'conv3x3_wino_kernel<64, 2>' if is_wino else 'conv3x3_halo_kernel'
+            kname = 'conv3x3_wino_kernel<64, 2, 1>' if is_wino else 'conv3x3_halo_kernel'
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32,
                 'traffic': traffic, 'traffic_source': traffic_src,
