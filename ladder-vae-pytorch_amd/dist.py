@@ -73,7 +73,9 @@ class GradAllReduce:
     `run()` is the non-overlapped form (everything after backward), kept for LVAE_DDP_MODE=split and for CPU/gloo tensors.
     """
 
-    def __init__(self, flat_grads, group=None, bucket_mb=8.0, segments=None):
+    def __init__(self, flat_grads, group=None, bucket_mb=None, segments=None):
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get('LVAE_BUCKET_MB', '8'))   # tuning switch (xGMI rings are per-link bound: see DESIGN.md §6)
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
