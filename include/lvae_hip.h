@@ -20,7 +20,8 @@
  *      LVAE_F32_SPLIT_WGRAD (1: the same six-product form for the fp32 weight gradient of the large 3x3 layers; read per call), LVAE_F32_SPLIT_WGRAD_MIN_M,
  *      LVAE_BF16_PERSISTENT (1: persistent form of the bf16 3x3 kernel, measured slower), LVAE_DISABLE_GATE_FWD_PERSISTENT, LVAE_GATE_FWD_WGS, LVAE_GATE_FWD_MIN_M, LVAE_GATE_FWD_WT (0: dword stores straight from the accumulators), LVAE_GATE_FWD_F32_SPLIT (1: six-product form, read per call),
  *      LVAE_GATE_BWD_F32_MFMA (1: the fused gate backward on the fp32 MFMA instead of its default six-product form, read per call),
- *      LVAE_WINO_WIDE (1: 256-pixel Winograd workgroups, one per CU, measured slower; read per call), LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
+ *      LVAE_WINO_SPLIT (0: the Winograd position GEMMs of the 64-channel layers on the fp32 MFMA instead of six exact bf16-piece products on the bf16 MFMA; read per call),
+ *      LVAE_WINO_WIDE (1: 256-pixel Winograd workgroups, one per CU, fp32-MFMA form only, measured slower; read per call), LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
  *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
  *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
  *    caller owns (ladder-vae-pytorch_amd/dist.py). SURVEY.md §8(b) sketched lvae_allreduce_{init,enqueue,wait,destroy}; they

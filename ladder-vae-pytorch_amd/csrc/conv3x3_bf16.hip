@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void bf_weight_kernel(BfPrepEntry e) { bf_prep
 // the entries of a batched pre-transform table (lvae_conv2d_prepare_weights) whose kind != 0; the Winograd kernel takes the others
 __global__ __launch_bounds__(256) void bf_weight_batched_kernel(const BfPrepEntry* __restrict__ entries) {
   const BfPrepEntry e = entries[blockIdx.y];
-  if (e.kind == 0) return;
+  if (e.kind != 1 && e.kind != 3) return;   // 0: Winograd fp32, 16: Winograd six-product form (conv3x3_wino.hip)
   bf_prep_element(e, blockIdx.x * 256 + threadIdx.x);
 }
 

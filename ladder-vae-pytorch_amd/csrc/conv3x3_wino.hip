@@ -22,20 +22,35 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "bf16_frag.h"
 #include "lvae_common.h"
 
 namespace lvae {
 
 struct WinoArgs {
   lvae_conv_desc d;
-  const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3
+  const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3; six-product form: bf16 [16][4 k16][Npad/32][3 pieces][64 lanes][8]
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, Cin;
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
 };
 
-// ---- weight transform: U[p] = (G g G^T)[p] with g[kh][kw] = w[tap(kh,kw)][k][n] (taps flipped for dgrad)
+// Six-product form (conv3x3_wino_kernel<.., SPL = true>): U[p][k][n] split exactly into three bf16 pieces, stored in the B-fragment order of
+// v_mfma_f32_32x32x16_bf16: [position 16][k16 step 4][32-channel output block][piece 3][lane 64][8], lane = 32 * ((k >> 3) & 1) + (n & 31),
+// element = k & 7, so that one wave load is 1 KB contiguous.
+__device__ __forceinline__ void store_u_split(__bf16* U3, int NB, int p, int k, int n, float v) {
+  const size_t base = (((size_t)(p * 4 + (k >> 4)) * NB + (n >> 5)) * 3 * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
+  float r = v;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const __bf16 b = (__bf16)r;
+    U3[base + (size_t)q * 512] = b;
+    r -= (float)b;  // exact: the remainder of a round-to-nearest to 8 bits has at most 16 significant bits
+  }
+}
+
+// ---- weight transform: U[p] = (G g G^T)[p] with g[kh][kw] = w[tap(kh,kw)][k][n] (taps flipped for dgrad); split != 0: store_u_split
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, int64_t stap, int64_t sk, int64_t sn,
-                                                           int K, int Kpad, int N, int Npad, int flip, float* __restrict__ U) {
+                                                           int K, int Kpad, int N, int Npad, int flip, float* __restrict__ U, int split) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Npad * Kpad) return;
   // consecutive threads -> consecutive floats of one position slab [8][2][Npad][4]
@@ -61,11 +76,20 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   const size_t slab = (size_t)Npad * Kpad;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    float* dst = U + (size_t)(a * 4) * slab + idx;
-    dst[0] = t[a][0];
-    dst[slab] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-    dst[2 * slab] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-    dst[3 * slab] = t[a][2];
+    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+    if (split) {
+      __bf16* U3 = reinterpret_cast<__bf16*>(U);
+      store_u_split(U3, Npad >> 5, a * 4, k, n, u0);
+      store_u_split(U3, Npad >> 5, a * 4 + 1, k, n, u1);
+      store_u_split(U3, Npad >> 5, a * 4 + 2, k, n, u2);
+      store_u_split(U3, Npad >> 5, a * 4 + 3, k, n, u3);
+    } else {
+      float* dst = U + (size_t)(a * 4) * slab + idx;
+      dst[0] = u0;
+      dst[slab] = u1;
+      dst[2 * slab] = u2;
+      dst[3 * slab] = u3;
+    }
   }
 }
 
@@ -82,7 +106,7 @@ static_assert(sizeof(WinoPrepEntry) == 64, "entry layout is part of the C ABI (l
 __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrepEntry* __restrict__ entries) {
   const WinoPrepEntry e = entries[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (e.pad_ != 0) return;  // a pre-split bf16 entry: conv3x3_bf16.hip's batched kernel handles it
+  if (e.pad_ != 0 && e.pad_ != 16) return;  // a pre-split bf16 entry of the direct kernel: conv3x3_bf16.hip's batched kernel handles it
   if (idx >= e.Npad * e.Kpad) return;
   const int c = idx & 3, n = (idx >> 2) % e.Npad, kq = (idx >> 2) / e.Npad;
   const int k = kq * 4 + c;
@@ -105,11 +129,20 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
   const size_t slab = (size_t)e.Npad * e.Kpad;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    float* dst = e.U + (size_t)(a * 4) * slab + idx;
-    dst[0] = t[a][0];
-    dst[slab] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-    dst[2 * slab] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-    dst[3 * slab] = t[a][2];
+    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+    if (e.pad_ == 16) {  // six-product form
+      __bf16* U3 = reinterpret_cast<__bf16*>(e.U);
+      store_u_split(U3, e.Npad >> 5, a * 4, k, n, u0);
+      store_u_split(U3, e.Npad >> 5, a * 4 + 1, k, n, u1);
+      store_u_split(U3, e.Npad >> 5, a * 4 + 2, k, n, u2);
+      store_u_split(U3, e.Npad >> 5, a * 4 + 3, k, n, u3);
+    } else {
+      float* dst = e.U + (size_t)(a * 4) * slab + idx;
+      dst[0] = u0;
+      dst[slab] = u1;
+      dst[2 * slab] = u2;
+      dst[3 * slab] = u3;
+    }
   }
 }
 
@@ -128,8 +161,16 @@ constexpr int WLDO = 68;  // R row stride (floats)
 // With one wave per SIMD nothing covers a wave's LDS round trips, the slice barriers or the prologue / epilogue of the only resident
 // workgroup, and re-reading U was not what held the two-workgroup form back (reading every k-step's fragments from one hot 8 KB
 // changed its time by 1 %).
-template <int CIN, int NH, int MT>
+//
+// SPL (six-product form, CIN = 64, MT = 1): the 16 position GEMMs run on the bf16 matrix unit. The input transform is done in fp32 exactly as
+// above, for 8 channels per lane and 16-channel step; each transformed value and each U element (pre-split by the weight transform) is an
+// exact sum of three bf16 pieces, and the six piece products of order <= 2^-16 are accumulated in fp32 (dropped terms < 2^-24 of a
+// product: fp32-equivalent, same parity tolerances). Why: v_mfma_f32_32x32x2_f32 executes on the vector ALU's lanes, so in the fp32 form
+// the kernel's 1,726 vector instructions per wave ADD to its 13.65 us of MFMA time (SQ counters: 50 % MFMA, 21 % VALU, 29 % parked);
+// v_mfma_f32_32x32x16_bf16 has its own unit, costs 6/16 per fp32-equivalent product and runs beside the vector work.
+template <int CIN, int NH, int MT, bool SPL>
 __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
+  static_assert(!SPL || (CIN == 64 && MT == 1 && NH == 2), "six-product form: 64 reduction channels, 128-pixel workgroups");
   constexpr int WLDA = CIN + 4;     // halo pixel stride (floats)
   constexpr int KSTEPS = CIN / 8, NSLICE = CIN / 16;
   constexpr int CW = 32 * NH;       // output channels of this workgroup
@@ -215,23 +256,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
     const int wimg = fastdiv(wt, a.m_wt_per_img), wr = wt - wimg * a.wt_per_img;
     const int wty = fastdiv(wr, a.m_tiles_x), wtx = wr - wty * a.tiles_x;
     const int pbase = (wimg * a.halo_h + 2 * wty) * a.halo_w + 2 * wtx;
-    pa[m] = As + (size_t)(pbase + ra * a.halo_w) * WLDA + 4 * lh;
-    pb[m] = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 4 * lh;
+    pa[m] = As + (size_t)(pbase + ra * a.halo_w) * WLDA + (SPL ? 8 : 4) * lh;
+    pb[m] = As + (size_t)(pbase + rb * a.halo_w) * WLDA + (SPL ? 8 : 4) * lh;
   }
-
-  // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
-  const size_t slab = (size_t)a.Npad * CIN;
-  const float* ub = a.U + (size_t)(4 * wave) * slab + ((size_t)lh * a.Npad + co0 + li) * 4;
-  const size_t kstep = (size_t)2 * a.Npad * 4;
-  f32x4 bf[RING][4][NH];
-  auto load_u = [&](int ks, int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int h = 0; h < NH; ++h) bf[buf][j][h] = *reinterpret_cast<const f32x4*>(ub + j * slab + ks * kstep + h * 128);
-  };
-#pragma unroll
-  for (int q = 0; q < RING - 1; ++q) load_u(q, q);
 
   f32x16 acc[MT][4][NH];
 #pragma unroll
@@ -246,39 +273,114 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
   store_slice(0);
   load_slice(1);
   __syncthreads();
+  if (!SPL) {
+    // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
+    const size_t slab = (size_t)a.Npad * CIN;
+    const float* ub = a.U + (size_t)(4 * wave) * slab + ((size_t)lh * a.Npad + co0 + li) * 4;
+    const size_t kstep = (size_t)2 * a.Npad * 4;
+    f32x4 bf[RING][4][NH];
+    auto load_u = [&](int ks, int buf) {
+  #pragma unroll
+      for (int j = 0; j < 4; ++j)
+  #pragma unroll
+        for (int h = 0; h < NH; ++h) bf[buf][j][h] = *reinterpret_cast<const f32x4*>(ub + j * slab + ks * kstep + h * 128);
+    };
+  #pragma unroll
+    for (int q = 0; q < RING - 1; ++q) load_u(q, q);
+
+  #pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + RING - 1 < KSTEPS) load_u(ks + RING - 1, (ks + RING - 1) % RING);
+      if (NH == 1) __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead: the scheduler otherwise sinks it next to its use
+  #pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        f32x4 tt[4];
+  #pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 da = *reinterpret_cast<const f32x4*>(pa[m] + c * WLDA + ks * 8);
+          const f32x4 db = *reinterpret_cast<const f32x4*>(pb[m] + c * WLDA + ks * 8);
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) tt[c][e] = __builtin_fmaf(sgn, db[e], da[e]);  // sgn = +-1: exact
+        }
+        f32x4 vv[4];
+        vv[0] = tt[0] - tt[2];
+        vv[1] = tt[1] + tt[2];
+        vv[2] = tt[2] - tt[1];
+        vv[3] = tt[1] - tt[3];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j)
+  #pragma unroll
+          for (int h = 0; h < NH; ++h)
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[m][j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks % RING][j][h][e], acc[m][j][h], 0, 0, 0);
+      }
+      if (NH == 1) __builtin_amdgcn_sched_barrier(0);
+      if ((ks & 1) && ks < KSTEPS - 1) {  // publish the next 16-channel slice, start fetching the one after
+        const int c = (ks + 1) >> 1;
+        store_slice(c);
+        if (c + 1 < NSLICE) load_slice(c + 1);
+        __syncthreads();
+      }
+    }
+  } else {
+    // ---- six-product form: U pieces of (position 4*wave + j, k16 step s, channel block h, piece q) are 1 KB wave loads. An (s, j)
+    // iteration is only 6 * NH MFMAs of 32 cycles, far shorter than an L2 round trip, so the pieces are fetched two iterations ahead
+    // (ring of 3, what 256 registers allow: 31.7 us with a ring of 2, 30.4 us with 3 at 256x16x16).
+    const int NB = a.Npad >> 5;
+    const __bf16* u3 = reinterpret_cast<const __bf16*>(a.U) + ((size_t)(co0 >> 5) * 3 * 64 + lane) * 8;
+    constexpr int BR = 3;
+    bf16x8 bq[BR][NH][3];
+    auto load_b = [&](int it, int buf) {  // it = 4 s + j
+      const __bf16* p = u3 + (size_t)((4 * wave + (it & 3)) * 4 + (it >> 2)) * NB * 1536;
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    if (ks + RING - 1 < KSTEPS) load_u(ks + RING - 1, (ks + RING - 1) % RING);
-    if (NH == 1) __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead: the scheduler otherwise sinks it next to its use
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      f32x4 tt[4];
+        for (int q = 0; q < 3; ++q) bq[buf][h][q] = *reinterpret_cast<const bf16x8*>(p + (h * 3 + q) * 512);
+    };
+#pragma unroll
+    for (int it = 0; it < (BR < 4 * NSLICE ? BR - 1 : BR); ++it) load_b(it, it);
+    // piece products in ascending order of magnitude: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int s16 = 0; s16 < NSLICE; ++s16) {
+      f32x4 tl[4], th[4];  // t = d[ra] + sgn * d[rb] for the four pixel columns, channels 16 s + 8 lh + {0..3 | 4..7}
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 da = *reinterpret_cast<const f32x4*>(pa[m] + c * WLDA + ks * 8);
-        const f32x4 db = *reinterpret_cast<const f32x4*>(pb[m] + c * WLDA + ks * 8);
+        const f32x4 dal = *reinterpret_cast<const f32x4*>(pa[0] + c * WLDA + s16 * 16);
+        const f32x4 dah = *reinterpret_cast<const f32x4*>(pa[0] + c * WLDA + s16 * 16 + 4);
+        const f32x4 dbl = *reinterpret_cast<const f32x4*>(pb[0] + c * WLDA + s16 * 16);
+        const f32x4 dbh = *reinterpret_cast<const f32x4*>(pb[0] + c * WLDA + s16 * 16 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tt[c][e] = __builtin_fmaf(sgn, db[e], da[e]);  // sgn = +-1: exact
+        for (int e = 0; e < 4; ++e) {
+          tl[c][e] = __builtin_fmaf(sgn, dbl[e], dal[e]);  // sgn = +-1: exact
+          th[c][e] = __builtin_fmaf(sgn, dbh[e], dah[e]);
+        }
       }
-      f32x4 vv[4];
-      vv[0] = tt[0] - tt[2];
-      vv[1] = tt[1] + tt[2];
-      vv[2] = tt[2] - tt[1];
-      vv[3] = tt[1] - tt[3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const int it = 4 * s16 + j;
+        if (BR < 4 * NSLICE && it + BR - 1 < 4 * NSLICE) load_b(it + BR - 1, (it + BR - 1) % BR);
+        const f32x4 vl = j == 0 ? tl[0] - tl[2] : (j == 1 ? tl[1] + tl[2] : (j == 2 ? tl[2] - tl[1] : tl[1] - tl[3]));
+        const f32x4 vh = j == 0 ? th[0] - th[2] : (j == 1 ? th[1] + th[2] : (j == 2 ? th[2] - th[1] : th[1] - th[3]));
+        bf16x4 pl[3], ph[3];
+        split4<3>(vl, pl);
+        split4<3>(vh, ph);
+        bf16x8 af[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[q] = bf16x8{pl[q][0], pl[q][1], pl[q][2], pl[q][3], ph[q][0], ph[q][1], ph[q][2], ph[q][3]};
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[m][j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][e], bf[ks % RING][j][h][e], acc[m][j][h], 0, 0, 0);
-    }
-    if (NH == 1) __builtin_amdgcn_sched_barrier(0);
-    if ((ks & 1) && ks < KSTEPS - 1) {  // publish the next 16-channel slice, start fetching the one after
-      const int c = (ks + 1) >> 1;
-      store_slice(c);
-      if (c + 1 < NSLICE) load_slice(c + 1);
-      __syncthreads();
+          for (int k = 0; k < 6; ++k)
+            acc[0][j][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bq[it % BR][h][PB[k]], acc[0][j][h], 0, 0, 0);
+      }
+      if (s16 < NSLICE - 1) {  // publish the next 16-channel slice, start fetching the one after
+        store_slice(s16 + 1);
+        if (s16 + 2 < NSLICE) load_slice(s16 + 2);
+        __syncthreads();
+      }
     }
   }
   __syncthreads();  // every wave is done with the halo patch: LDS becomes R[wave][b][tile][co]
@@ -372,8 +474,37 @@ static bool al16w2(const void* p) { return p == nullptr || (reinterpret_cast<uin
 static int wino_kpad(const lvae_conv_desc* d) { return d->C1 <= 64 ? 64 : 128; }
 static bool kpad_is64(const lvae_conv_desc* d) { return d->C1 <= 64; }
 
+static bool wino_tile_for(const lvae_conv_desc* d, int budget, int max_halo, int& TH, int& NI) {
+  TH = 0;
+  for (int c = 2; c <= d->H; c += 2)
+    if (d->H % c == 0 && c * d->W <= budget) TH = c;
+  if (TH == 0) return false;
+  NI = TH < d->H ? 1 : budget / (TH * d->W);
+  if (NI < 1) NI = 1;
+  if (NI > d->N) NI = d->N;
+  return NI * (TH + 2) * (d->W + 2) <= max_halo;
+}
+
+// layers with fewer pixel tiles than CUs run 32-channel workgroups (conv3x3_wino_kernel<64, 1, 1, false>)
+static bool wino_narrow(const lvae_conv_desc* d, int TH, int NI) {
+  static const int narrow_tiles = getenv("LVAE_WINO_NARROW_TILES") ? atoi(getenv("LVAE_WINO_NARROW_TILES")) : 256;  // tuning switch
+  return kpad_is64(d) && ((d->N + NI - 1) / NI) * (d->H / TH) < narrow_tiles;
+}
+
+// six-product form (conv3x3_wino_kernel<64, 2, 1, true>): fp32 precision, 64 reduction channels, at least 256 pixel tiles (the
+// 32-channel workgroups of smaller layers are latency chains, one wave per SIMD: 17.5 us in this form against 16.4 us on the fp32 MFMA);
+// LVAE_WINO_SPLIT=0 keeps the fp32 MFMA everywhere (read per call: the parity tests run both forms in one process)
+static bool wino_split_form(const lvae_conv_desc* d) {
+  if (d->precision != LVAE_PREC_F32 || !kpad_is64(d)) return false;
+  const char* sw = getenv("LVAE_WINO_SPLIT");
+  if (sw != nullptr && atoi(sw) == 0) return false;
+  int TH, NI;
+  return wino_tile_for(d, 128, 256, TH, NI) && !wino_narrow(d, TH, NI);
+}
+
 size_t conv3x3_wino_workspace(const lvae_conv_desc* d) {
   const int ntn = (d->Cout + 63) / 64;
+  if (wino_split_form(d)) return (size_t)16 * 4 * (2 * ntn) * 3 * 1024;  // bf16 pieces [16][4 k16][Npad/32][3][64 lanes][8]
   return (size_t)16 * ntn * 64 * wino_kpad(d) * sizeof(float);  // 16 position slabs [Kpad/8][2][Npad][4]
 }
 
@@ -397,22 +528,11 @@ struct WinoTile {
   int TH, NI, mt;
 };
 
-static bool wino_tile_for(const lvae_conv_desc* d, int budget, int max_halo, int& TH, int& NI) {
-  TH = 0;
-  for (int c = 2; c <= d->H; c += 2)
-    if (d->H % c == 0 && c * d->W <= budget) TH = c;
-  if (TH == 0) return false;
-  NI = TH < d->H ? 1 : budget / (TH * d->W);
-  if (NI < 1) NI = 1;
-  if (NI > d->N) NI = d->N;
-  return NI * (TH + 2) * (d->W + 2) <= max_halo;
-}
-
 static bool wino_tile(const lvae_conv_desc* d, WinoTile& w) {
   const char* wsw = getenv("LVAE_WINO_WIDE");  // experiment switch, read per call (the parity tests run both forms in one process)
   const bool wide_on = wsw != nullptr && atoi(wsw) != 0;
   int TH, NI;
-  if (wide_on && kpad_is64(d) && wino_tile_for(d, 256, 384, TH, NI)) {
+  if (wide_on && kpad_is64(d) && !wino_split_form(d) && wino_tile_for(d, 256, 384, TH, NI)) {
     const int64_t groups = (int64_t)((d->N + NI - 1) / NI) * (d->H / TH) * ((d->Cout + 63) / 64);
     if (groups >= 256) {
       w = WinoTile{TH, NI, 2};
@@ -443,6 +563,7 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   WinoTile wtile;
   if (!wino_tile(d, wtile)) return -1000;
   const int TH = wtile.TH, NI = wtile.NI, mt = wtile.mt;
+  const bool split = wino_split_form(d);
   a.TH = TH;
   a.TW = d->W;
   a.NI = NI;
@@ -454,9 +575,7 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.wt_per_img = (TH / 2) * a.tiles_x;
   a.n_wt = NI * a.wt_per_img;
   a.Npad = (d->Cout + 63) / 64 * 64;
-  const int img_groups_ = (d->N + NI - 1) / NI;
-  static const int narrow_tiles = getenv("LVAE_WINO_NARROW_TILES") ? atoi(getenv("LVAE_WINO_NARROW_TILES")) : 256;  // tuning switch
-  const bool narrow = mt == 1 && kpad_is64(d) && img_groups_ * a.tiles_h < narrow_tiles;  // fewer pixel tiles than CUs: 32-channel workgroups
+  const bool narrow = mt == 1 && wino_narrow(d, TH, NI);  // fewer pixel tiles than CUs: 32-channel workgroups
   a.ntn = narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64;
   a.m_thw = fastdiv_magic(TH * d->W);
   a.m_tw = fastdiv_magic(d->W);
@@ -472,10 +591,11 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   if (lds > 160 * 1024) return -1000;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -487,15 +607,16 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   const int Npad = a.Npad;
   if (!d->workspace_ready) {
     hipLaunchKernelGGL(wino_weight_kernel, dim3((Npad * kpad + 255) / 256), dim3(256), 0, s, d->w, d->w_stap, d->w_sk, d->w_sn, Cin,
-                       kpad, d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U);
+                       kpad, d->Cout, Npad, d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0, U, split ? 1 : 0);
     LVAE_LAUNCH_CHECK("wino_weight");
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (mt == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 2>), grid, dim3(256), lds, s, a);
-  else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1>), grid, dim3(256), lds, s, a);
-  else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2, 1>), grid, dim3(256), lds, s, a);
+  if (mt == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 2, false>), grid, dim3(256), lds, s, a);
+  else if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
+  else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1, false>), grid, dim3(256), lds, s, a);
+  else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, false>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2, 1, false>), grid, dim3(256), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wino");
   return 0;
 }
@@ -539,7 +660,7 @@ extern "C" int lvae_conv2d_prepare_entry(const lvae_conv_desc* d, void* entry) {
   e.Npad = (d->Cout + 63) / 64 * 64;
   e.flip = d->gather == LVAE_GATHER_TRANSPOSED ? 1 : 0;
   e.Kpad = wino_kpad(d);
-  e.pad_ = 0;
+  e.pad_ = wino_split_form(d) ? 16 : 0;  // kind: 0 fp32 position slabs, 16 six-product bf16 pieces (1 / 3: conv3x3_bf16.hip's entries)
   memcpy(entry, &e, sizeof(e));
   return 0;
 }

@@ -112,15 +112,18 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize('form', ['winograd', 'split'])
+@pytest.mark.parametrize('form', ['winograd', 'winograd6', 'split'])
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv3x3_winograd(K, case, form, monkeypatch):
-    """Large 3x3 stride-1 layers run either as Winograd F(2x2,3x3) on the fp32 MFMA (LVAE_F32_SPLIT=0) or as six exact bf16-piece
-    products per fp32 product on the bf16 MFMA (the default where the shape fits); both must agree with the direct sum to a few
-    ulp of fp32, including the fused BN/activation prologue and dropout/activation epilogue."""
-    monkeypatch.setenv('LVAE_F32_SPLIT', '0' if form == 'winograd' else '1')
-    monkeypatch.setenv('LVAE_F32_SPLIT_WGRAD', '0' if form == 'winograd' else '1')   # weight gradient: fp32 MFMA / six-product bf16 form
-    monkeypatch.setenv('LVAE_WINO_WIDE', '1' if case[0] in (257, 65, 130) or case == (300, 32, 24, 16) else '0')   # 256-pixel workgroups (MT = 2)
+    """Large 3x3 stride-1 layers in fp32 run as Winograd F(2x2,3x3) with the 16 position GEMMs either on the fp32 MFMA ('winograd',
+    LVAE_WINO_SPLIT=0) or as six exact bf16-piece products per fp32 product on the bf16 MFMA ('winograd6', the default), or as a direct
+    convolution in the six-product form ('split', LVAE_F32_SPLIT=1); all must agree with the direct sum to a few ulp of fp32, including
+    the fused BN/activation prologue and dropout/activation epilogue."""
+    monkeypatch.setenv('LVAE_F32_SPLIT', '1' if form == 'split' else '0')
+    monkeypatch.setenv('LVAE_WINO_SPLIT', '1' if form == 'winograd6' else '0')
+    monkeypatch.setenv('LVAE_F32_SPLIT_WGRAD', '1' if form == 'split' else '0')   # weight gradient: fp32 MFMA / six-product bf16 form
+    wide = form == 'winograd' and (case[0] in (257, 65, 130) or case == (300, 32, 24, 16))
+    monkeypatch.setenv('LVAE_WINO_WIDE', '1' if wide else '0')   # 256-pixel workgroups (MT = 2), fp32 MFMA form only
     N, Co, H, W = case
     C = 64
     g = torch.Generator().manual_seed(sum(case))
@@ -134,7 +137,7 @@ def test_conv3x3_winograd(K, case, form, monkeypatch):
     wp = packed_weight(w)
     geom = K.ConvGeom(wp, 1, 1)
     d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
-    if form == 'winograd':
+    if form != 'split':
         assert K._C.load().lvae_conv2d_workspace(ctypes.byref(d)) > 0, "case is meant to exercise the Winograd path"
     yd = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
                   out_scale=drop.cuda(), out_act='elu')
