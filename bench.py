@@ -286,16 +286,32 @@ def main():
         if args.dtype == 'f32':
             issued = 16.0 / 36.0 if is_wino else 1.0
             traffic, traffic_src = pmc_traffic(dkey, is_wino)
-            kname = 'conv3x3_wino_kernel<64, 2, 1>' if is_wino else 'conv3x3_halo_kernel'
+            six = is_wino and os.environ.get('LVAE_WINO_SPLIT', '1') != '0'   # the library's default form for this layer shape
+            kname = ('conv3x3_wino_kernel<64, 2, 1, true>' if six else 'conv3x3_wino_kernel<64, 2, 1, false>') if is_wino else 'conv3x3_halo_kernel'
+            PEAK_MFMA_BF16 = 2500.0  # TFLOP/s dense, MI355X_MICROARCH.md
+            if six:
+                note = ('achieved/frac count ALGORITHMIC direct-convolution fp32 FLOPs (2*N*OH*OW*Cout*Cin*KH*KW per launch) against the '
+                        'fp32-MFMA peak, as the contract asks for an fp32 path. The kernel is Winograd F(2x2,3x3) (16/36 of those '
+                        'multiplies) whose position GEMMs run as six exact bf16-piece products per fp32 product on the bf16 matrix unit '
+                        '(fp32-equivalent results), so frac may exceed 1: the fp32 MFMA is no longer the unit it runs on. What the bf16 '
+                        'unit really does is bf16_mfma_issued_frac of ITS dense peak; the kernel is bound by vector instructions and '
+                        'latency (SQ counters in profiles/r02_pmc/wino_sq_counters.txt: VALU 39 %, MFMA 24 % beside it, waves parked 46 %), '
+                        'and moves algorithmic_bytes_per_launch / avg launch time = hbm_frac_of_peak of the HBM peak')
+            else:
+                note = ('achieved/frac count ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*KH*KW per launch) as the contract '
+                        'asks; the kernel is Winograd F(2x2,3x3) and issues 16/36 of them, so the matrix pipe itself is mfma_issued_frac '
+                        'busy and the kernel runs at frac_of_winograd_floor of its own MFMA floor')
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32,
                 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': '%s (forward + dgrad launches of: %s)' % (kname, dkey),
-                'note': 'achieved/frac count ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*KH*KW per launch) as the contract '
-                        'asks; the kernel is Winograd F(2x2,3x3) and issues 16/36 of them, so the matrix pipe itself is mfma_issued_frac '
-                        'busy and the kernel runs at frac_of_winograd_floor of its own MFMA floor',
-                'mfma_flops_issued_fraction': issued, 'mfma_issued_frac': ach * issued / PEAK_MFMA_F32,
-                'frac_of_winograd_floor': ach * issued / PEAK_MFMA_F32 if is_wino else None,
+                'note': note,
+                'mfma_unit': 'bf16 (six-product fp32-equivalent form)' if six else 'fp32',
+                'mfma_flops_issued_fraction': issued * (6.0 if six else 1.0),
+                'mfma_issued_frac': None if six else ach * issued / PEAK_MFMA_F32,
+                'bf16_mfma_issued_frac': ach * issued * 6.0 / PEAK_MFMA_BF16 if six else None,
+                'frac_of_winograd_floor': None if six or not is_wino else ach * issued / PEAK_MFMA_F32,
+                'hbm_frac_of_peak': (dbytes / dn) / (per_launch_us * 1e-6) / 1e9 / PEAK_HBM,
                 'launches_per_step': dn, 'avg_launch_us': per_launch_us,
                 'avg_launch_us_rocprof': rocprof_avg_us(kname, 512), 'rocprof_summary': ROCPROF_SUMMARY,
                 'flops_per_launch': dflops / dn, 'algorithmic_bytes_per_launch': dbytes / dn,
