@@ -105,7 +105,8 @@ typedef struct lvae_conv_desc {
   int32_t KH, KW, stride, pad;
   int32_t gather;        /* LVAE_GATHER_* */
   int32_t precision;     /* LVAE_PREC_F32 (0): results as an fp32 multiply-add chain (fp32 MFMA, Winograd, or six exact bf16-piece
-                            products per fp32 product); LVAE_PREC_BF16: operands rounded to bf16 at the matrix-core input, fp32
+                            products per fp32 product: finite inputs only differ from the fp32 MFMA by terms below 2^-24 of a product;
+                            an infinite operand gives NaN there, where an fp32 multiply would give +-inf); LVAE_PREC_BF16: operands rounded to bf16 at the matrix-core input, fp32
                             accumulate (kernel variants that have no bf16 form run in fp32) */
   void* workspace;       /* scratch for lvae_conv2d_f32 (transformed weights of the Winograd path) or NULL */
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
