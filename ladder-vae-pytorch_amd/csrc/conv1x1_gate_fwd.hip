@@ -9,9 +9,11 @@
 //   * at most 512 workgroups (two per CU), each walking over tiles blockIdx.x, blockIdx.x + gridDim.x, ...;
 //   * W lives in registers for the life of the workgroup (64 VGPRs per lane: the B operand of every v_mfma_f32_32x32x2_f32 this wave
 //     issues), so the only LDS traffic is the x tile, double-buffered: tile i+1 is fetched while tile i is in the MFMAs and the epilogue;
-//   * the epilogue works on the accumulators as they stand: one accumulator register across a wave is two 128-byte row segments, which
-//     is a full-rate store shape, and the a- and b-halves of a channel sit in the same lane (wave wn owns columns wn*32 + lane and
-//     64 + wn*32 + lane), so ab, the gate, the residual add and the statistics need no LDS round trip; the residual rows are requested
+//   * the a- and b-halves of a channel sit in the same lane (wave wn owns columns wn*32 + lane and 64 + wn*32 + lane), so bias, gate and
+//     statistics are lane-local arithmetic on the accumulators and the epilogue needs no workgroup barrier. Two store forms: (WT, the
+//     default) each output passes through a 5 KB LDS strip private to the wave, which turns the accumulator layout into 16-byte rows
+//     for write-through stores (20.3 us at 256x16x16); (!WT) one dword per lane straight from the accumulators - an accumulator
+//     register across a wave is two 128-byte row segments, a full-rate shape for plain stores (22.0 us). The residual rows are requested
 //     before the MFMAs of their tile.
 #include <stdlib.h>
 
