@@ -10,7 +10,7 @@ import lvae_amd  # noqa: F401
 from lvae_amd import kernels as K
 from conv_bench import packed
 
-B, C, H = 256, 64, 16
+B, C, H = 256, 64, int(os.environ.get("PMC_H", "16"))
 x = torch.randn(B, H, H, C, device='cuda')
 w = packed(C, C, 3)
 g = K.ConvGeom(w, 1, 1)
