@@ -215,6 +215,20 @@ def main():
     from lvae_amd.engine import TrainStep
 
     rank, world, local = ldist.init_from_env(args.backend)
+    if world > 1:
+        # A multi-rank run that stops making progress (a collective one rank never enters) must not sit on the node until the caller's
+        # limit: after LVAE_BENCH_WATCHDOG_S seconds (default 900) the rank says where it was and exits non-zero, which ends the job.
+        import threading
+        limit = float(os.environ.get('LVAE_BENCH_WATCHDOG_S', '900'))
+
+        def _expired():
+            log('rank %d: no result after %.0f s (LVAE_BENCH_WATCHDOG_S); LVAE_DDP_MODE=split keeps the gradient exchange outside '
+                'the step graph if the captured exchange is what hangs' % (rank, limit))
+            os._exit(3)
+
+        watchdog = threading.Timer(limit, _expired)
+        watchdog.daemon = True
+        watchdog.start()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
