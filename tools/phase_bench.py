@@ -1,5 +1,5 @@
 """Phase-skip timing of conv3x3_bf16 (needs a -DLVAE_PHASE_DEBUG build: make EXTRA=-DLVAE_PHASE_DEBUG); LVAE_BF16_DEBUG is read once
-per process, so each configuration runs in its own process: python tools/phase_bench.py <H> <prec>"""
+per process, so each configuration runs in its own process: python tools/phase_bench.py <H> <prec> [path of the debug liblvae_hip.so]"""
 import os
 import sys
 
@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import lvae_amd  # noqa: F401
+from lvae_amd import _C
+if len(sys.argv) > 3:
+    _C.LIB_PATH = sys.argv[3]   # the debug build made by tools/phase_run.sh in a scratch directory
 from lvae_amd import kernels as K
 from conv_bench import packed, timeit
 
