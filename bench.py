@@ -35,7 +35,19 @@ PEAK_MFMA_F32 = 157.3   # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0       # GB/s, MI355X_MICROARCH.md (spec; 6.3 TB/s is what a streaming copy achieves)
 F_ALG_PER_IMAGE = 10.563e9     # FLOP, fwd + dgrad + wgrad of every convolution
 B_ALG_PER_IMAGE = 115.93e6     # bytes, fp32 activations in/out of every convolution, fwd + dgrad + wgrad
-ROCPROF_SUMMARY = 'profiles/r02_kernel_by_grid.txt'   # committed rocprofv3 --kernel-trace summary of this command
+B_ALG_PER_IMAGE_BF16 = 57.96e6  # bytes, the same tensors stored in bf16 (BASELINE.md §4 counts 2 B per element)
+PEAK_MFMA_BF16 = 2500.0        # TFLOP/s dense, MI355X_MICROARCH.md
+# committed rocprofv3 summaries of this command (newest round first; tools/r03_final.sh writes them)
+ROCPROF_SUMMARIES = ('profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
+PMC_SUMMARIES = ('profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
+PMC_SUMMARIES_BF16 = ('profiles/r03_pmc/hbm_traffic_bf16.json',)
+
+
+def first_existing(paths):
+    for rel in paths:
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel
+    return None
 
 
 def host_cores():
@@ -63,7 +75,7 @@ def conv_roofline(model, x):
     from lvae_amd import kernels as K
     from lvae_amd.engine import forward_pass
     rec = []
-    wino, bf16 = set(), set()
+    variants = {}
     orig = K.call
 
     def timed_call(name, *args):
@@ -75,8 +87,8 @@ def conv_roofline(model, x):
             flops /= d.stride * d.stride  # taps that hit no input pixel are not algorithmic work
         nbytes = 4.0 * (d.N * d.H * d.W * (d.C1 + d.C2) + d.N * d.OH * d.OW * d.Cout + d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
         key = 'conv %dx%d s%d %d->%d @%dx%dx%d' % (d.KH, d.KW, d.stride, d.C1 + d.C2, d.Cout, d.N, d.OH, d.OW)
-        if name == 'lvae_conv2d_f32' and K._C.load().lvae_conv2d_workspace(args[0]) > 0:
-            (wino if d.precision == 0 else bf16).add(key)
+        if name == 'lvae_conv2d_f32':
+            variants[key] = K._C.load().lvae_conv2d_variant(args[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig(name, *args)
@@ -102,13 +114,13 @@ def conv_roofline(model, x):
     dom = max(groups.items(), key=lambda kv: kv[1][3])
     fam_f = sum(g[1] for g in groups.values())
     fam_ms = sum(g[3] for g in groups.values())
-    return dom, fam_f, fam_ms, len(rec), ('wino' if dom[0] in wino else 'bf16' if dom[0] in bf16 else 'other')
+    return dom, fam_f, fam_ms, len(rec), variants.get(dom[0], 0)
 
 
 def pmc_traffic(dom_key, is_wino):
     """HBM bytes per launch of the dominant kernel from a committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 half-count correction). Returns (bytes | None, source)."""
-    for rel in ('profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json'):
+    for rel in PMC_SUMMARIES:
         path = os.path.join(ROOT, rel)
         if dom_key != 'conv 3x3 s1 64->64 @256x16x16' or not os.path.exists(path):
             continue
@@ -120,12 +132,21 @@ def pmc_traffic(dom_key, is_wino):
     return None, None
 
 
+def pmc_step(paths=PMC_SUMMARIES):
+    """(HBM bytes of one whole training step measured by the committed PMC run, its file) or (None, None)."""
+    rel = first_existing(paths)
+    if rel is None:
+        return None, None
+    st = json.load(open(os.path.join(ROOT, rel))).get('step')
+    return (st['hbm_bytes_per_step'], rel) if st else (None, None)
+
+
 def rocprof_avg_us(kernel_prefix, wgs):
     """Average duration of `kernel_prefix` at `wgs` workgroups from the committed rocprofv3 --kernel-trace summary."""
-    path = os.path.join(ROOT, ROCPROF_SUMMARY)
-    if not os.path.exists(path):
+    rel = first_existing(ROCPROF_SUMMARIES)
+    if rel is None:
         return None
-    for line in open(path):
+    for line in open(os.path.join(ROOT, rel)):
         if line.startswith(kernel_prefix) and ('wgs=%6d' % wgs) in line and 'avg=' in line:
             return float(line.split('avg=')[1].split()[0])
     return None
@@ -190,6 +211,100 @@ def time_steps(step, ring, n, world, dev):
     return dt, out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as CHILD processes through torch.distributed.run
+    — before this process has made any GPU call, and never by exec — relay rank 0's JSON line and exit non-zero if any child does."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this platform (RCCL across processes)
+    env['LVAE_BENCH_SELF_LAUNCHED'] = '1'
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // max(1, args.gpus))))
+    log('no WORLD_SIZE in the environment: starting %d ranks as child processes (%s)' % (args.gpus, ' '.join(cmd[1:8])))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip('\n')
+        if out.startswith('{') and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        raise SystemExit(rc if rc != 0 else 4)
+    raise SystemExit(0)
+
+
+def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
+    """Roofline record of the dominant kernel. `frac` = matrix FLOPs the kernel ISSUES per launch / average launch time / the dense
+    peak of the unit that issues them; the algorithmic direct-convolution rate is kept as `effective_tflops`."""
+    from lvae_amd import kernels as K
+    t = dms * 1e-3 / dn                       # seconds per launch (HIP events on the launch stream)
+    f_alg, b_alg = dflops / dn, dbytes / dn
+    V = K._C
+    if kind == V.VARIANT_WINO_SIX:   # Winograd F(2x2,3x3): 16/36 of the direct multiplies, each as six bf16-piece products on the bf16 MFMA
+        issued, peak, unit = f_alg * 16.0 / 36.0 * 6.0, PEAK_MFMA_BF16, 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), six exact bf16-piece products per fp32 product'
+        kname = 'conv3x3_wino_kernel<64, 2, 1, true>'
+    elif kind == V.VARIANT_WINO_F32:
+        issued, peak, unit, kname = f_alg * 16.0 / 36.0, PEAK_MFMA_F32, 'fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'conv3x3_wino_kernel<64, 2, 1, false>'
+    elif kind == V.VARIANT_BF16_DIRECT:
+        issued, peak, unit, kname = f_alg, PEAK_MFMA_BF16, 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 operands', 'conv3x3_bf16_kernel<1, *>'
+    elif kind == V.VARIANT_SIX_DIRECT:
+        issued, peak, unit, kname = 6 * f_alg, PEAK_MFMA_BF16, 'bf16 MFMA, six-product direct form', 'conv3x3_bf16_kernel<3, *>'
+    else:
+        issued, peak, unit, kname = f_alg, PEAK_MFMA_F32, 'fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'conv3x3_pos_kernel / conv3x3_halo_kernel / conv1x1_kernel / conv_igemm_kernel'
+    ach = issued / t / 1e12
+    hbm = b_alg / t / 1e9
+    traffic, traffic_src = pmc_traffic(dkey, kind in (V.VARIANT_WINO_SIX, V.VARIANT_WINO_F32)) if dtype == 'f32' else (None, None)
+    rec = {
+        'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+        'traffic': traffic, 'traffic_source': traffic_src,
+        'kernel': '%s (forward + dgrad launches of: %s)' % (kname, dkey),
+        'mfma_unit': unit, 'issued_flops_per_launch': issued, 'algorithmic_flops_per_launch': f_alg,
+        'effective_tflops': f_alg / t / 1e12,
+        'effective_frac_of_fp32_mfma_peak': f_alg / t / 1e12 / PEAK_MFMA_F32,
+        'algorithmic_bytes_per_launch': b_alg, 'hbm_gb_per_s': hbm, 'hbm_frac_of_peak': hbm / PEAK_HBM,
+        'launches_per_step': dn, 'avg_launch_us': t * 1e6,
+        'avg_launch_us_rocprof': rocprof_avg_us(kname, 512), 'rocprof_summary': first_existing(ROCPROF_SUMMARIES),
+        'note': 'frac = FLOPs the matrix unit ISSUES per launch / avg launch time / that unit\'s dense peak. effective_tflops counts the '
+                'ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*9) the launch replaces. The kernel is bound by neither pipe peak: '
+                'see the SQ counters named in DESIGN.md §5 (vector instructions per MFMA, parked waves).',
+    }
+    if kind == V.VARIANT_BF16_DIRECT:
+        rec['bound'] = 'hbm' if hbm / PEAK_HBM > ach / peak else 'mfma'
+        if rec['bound'] == 'hbm':
+            rec.update({'achieved': hbm, 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': hbm / PEAK_HBM, 'mfma_frac': ach / peak})
+    return rec
+
+
+def step_record(step_s, batch, dtype):
+    """Whole-step fractions: algorithmic conv FLOPs / bytes over the step time, and — from the committed PMC run —
+    the HBM bytes the step really moves."""
+    b_alg = (B_ALG_PER_IMAGE_BF16 if dtype == 'bf16' else B_ALG_PER_IMAGE) * batch
+    f_alg = F_ALG_PER_IMAGE * batch
+    rec = {'algorithmic_tflops': f_alg / step_s / 1e12, 'algorithmic_gb_per_s': b_alg / step_s / 1e9,
+           'hbm_frac': b_alg / step_s / 1e9 / PEAK_HBM,
+           'hbm_floor_ms': b_alg / (PEAK_HBM * 1e9) * 1e3, 'target_ms_at_half_hbm_roof': 2 * b_alg / (PEAK_HBM * 1e9) * 1e3,
+           'mfma_f32_frac': f_alg / step_s / 1e12 / PEAK_MFMA_F32,
+           'compute_floor_ms': {'fp32_mfma_direct': f_alg / (PEAK_MFMA_F32 * 1e12) * 1e3,
+                                'bf16_mfma_six_product_direct': 6 * f_alg / (PEAK_MFMA_BF16 * 1e12) * 1e3,
+                                'bf16_mfma_six_product_winograd': 6 * f_alg * 16 / 36 / (PEAK_MFMA_BF16 * 1e12) * 1e3,
+                                'bf16_mfma_bf16_operands': f_alg / (PEAK_MFMA_BF16 * 1e12) * 1e3}}
+    measured, src = pmc_step(PMC_SUMMARIES_BF16 if dtype == 'bf16' else PMC_SUMMARIES)
+    if measured is not None:
+        rec.update({'measured_hbm_bytes': measured, 'measured_hbm_frac': measured / step_s / 1e9 / PEAK_HBM,
+                    'traffic_ratio': measured / b_alg, 'measured_hbm_source': src})
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -206,7 +321,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-bf16-line', action='store_true', help='skip the nested bf16_shard measurement of the default fp32 run')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='rendezvous rehearsal without a GPU: every rank joins the process group (use --backend gloo), all-reduces one host '
+                         'scalar and rank 0 prints a JSON line; exercises the self-launch path of --gpus N (tests/test_dist_cpu.py)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and os.environ.get('LVAE_FORCE_DIST') != '1':
+        self_launch(args, sys.argv[1:])   # never returns
 
     from lvae_amd import dist as ldist
     from lvae_amd.models.lvae import LadderVAE
@@ -215,6 +336,19 @@ def main():
     from lvae_amd.engine import TrainStep
 
     rank, world, local = ldist.init_from_env(args.backend)
+    if args.launch_check:
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'metric': 'launch-check', 'value': float(t.item()), 'n_gpus': world, 'backend': args.backend,
+                              'self_launched': os.environ.get('LVAE_BENCH_SELF_LAUNCHED') == '1'}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        if os.environ.get('LVAE_LAUNCH_CHECK_FAIL_RANK') == str(rank):
+            raise SystemExit(7)   # rehearses "one child fails": the parent must exit non-zero
+        return
     if world > 1:
         # A multi-rank run that stops making progress (a collective one rank never enters) must not sit on the node until the caller's
         # limit: after LVAE_BENCH_WATCHDOG_S seconds (default 900) the rank says where it was and exits non-zero, which ends the job.
@@ -279,70 +413,24 @@ def main():
             'config': {'workload': 'CIFAR10-shaped 15-layer LVAE (BASELINE configs[%d]): 32x32x3, zdims 32x15, 4 blocks/layer, '
                                    '64 filters, gated+skip, DMoL-10, dropout 0.2, free bits 1.0' % (2 if args.dtype == 'f32' else 3),
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
-                       'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph},
+                       'parallelism': 'dp%d' % world, 'hip_graph': step.use_graph},
             'neg_elbo': -elbo, 'loss': loss,
         }
-        if world > 1 and allreduce is not None:
-            line['config']['grad_exchange'] = ('%d completion-ordered buckets on a side stream during backward, inside the step graph'
-                                               % len(allreduce.buckets)) if step.overlap else 'after backward (LVAE_DDP_MODE=split)'
+        if allreduce is not None and allreduce.active:
+            line['config']['grad_exchange'] = step.exchange_description()
+            line['config']['allreduce_bytes_per_step'] = 4 * arena.grads.numel()
+            line['config']['allreduce_buckets'] = len(allreduce.buckets)
+            line['config']['allreduce_bucket_bytes'] = [4 * (hi - lo) for lo, hi, _ in allreduce.buckets]
+            line['config']['backend'] = dist.get_backend() if dist.is_initialized() else None
     step_s = dt / args.steps
     if rank == 0 and not args.no_roofline:
         (dkey, (dn, dflops, dbytes, dms)), fam_f, fam_ms, n, kind = conv_roofline(model, ring[0])
-        is_wino = kind == 'wino'
-        ach = dflops / (dms * 1e-3) / 1e12
-        per_launch_us = dms * 1e3 / dn
-        step_rf = {'mfma_f32_frac': F_ALG_PER_IMAGE * args.batch / step_s / 1e12 / PEAK_MFMA_F32,
-                   'hbm_frac': B_ALG_PER_IMAGE * args.batch / step_s / 1e9 / PEAK_HBM,
-                   'algorithmic_tflops': F_ALG_PER_IMAGE * args.batch / step_s / 1e12,
-                   'algorithmic_gb_per_s': B_ALG_PER_IMAGE * args.batch / step_s / 1e9,
-                   'binding_roof': 'mfma-f32 (floor %.1f ms/step; HBM floor %.1f ms)' % (
-                       F_ALG_PER_IMAGE * args.batch / (PEAK_MFMA_F32 * 1e12) * 1e3, B_ALG_PER_IMAGE * args.batch / (PEAK_HBM * 1e9) * 1e3)}
-        if args.dtype == 'f32':
-            issued = 16.0 / 36.0 if is_wino else 1.0
-            traffic, traffic_src = pmc_traffic(dkey, is_wino)
-            six = is_wino and os.environ.get('LVAE_WINO_SPLIT', '1') != '0'   # the library's default form for this layer shape
-            kname = ('conv3x3_wino_kernel<64, 2, 1, true>' if six else 'conv3x3_wino_kernel<64, 2, 1, false>') if is_wino else 'conv3x3_halo_kernel'
-            PEAK_MFMA_BF16 = 2500.0  # TFLOP/s dense, MI355X_MICROARCH.md
-            if six:
-                note = ('achieved/frac count ALGORITHMIC direct-convolution fp32 FLOPs (2*N*OH*OW*Cout*Cin*KH*KW per launch) against the '
-                        'fp32-MFMA peak, as the contract asks for an fp32 path. The kernel is Winograd F(2x2,3x3) (16/36 of those '
-                        'multiplies) whose position GEMMs run as six exact bf16-piece products per fp32 product on the bf16 matrix unit '
-                        '(fp32-equivalent results), so frac may exceed 1: the fp32 MFMA is no longer the unit it runs on. What the bf16 '
-                        'unit really does is bf16_mfma_issued_frac of ITS dense peak; the kernel is bound by vector instructions and '
-                        'latency (SQ counters in profiles/r02_pmc/wino_sq_counters.txt: VALU 39 %, MFMA 24 % beside it, waves parked 46 %), '
-                        'and moves algorithmic_bytes_per_launch / avg launch time = hbm_frac_of_peak of the HBM peak')
-            else:
-                note = ('achieved/frac count ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*KH*KW per launch) as the contract '
-                        'asks; the kernel is Winograd F(2x2,3x3) and issues 16/36 of them, so the matrix pipe itself is mfma_issued_frac '
-                        'busy and the kernel runs at frac_of_winograd_floor of its own MFMA floor')
-            line['roofline'] = {
-                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_F32, 'unit': 'TFLOP/s', 'frac': ach / PEAK_MFMA_F32,
-                'traffic': traffic, 'traffic_source': traffic_src,
-                'kernel': '%s (forward + dgrad launches of: %s)' % (kname, dkey),
-                'note': note,
-                'mfma_unit': 'bf16 (six-product fp32-equivalent form)' if six else 'fp32',
-                'mfma_flops_issued_fraction': issued * (6.0 if six else 1.0),
-                'mfma_issued_frac': None if six else ach * issued / PEAK_MFMA_F32,
-                'bf16_mfma_issued_frac': ach * issued * 6.0 / PEAK_MFMA_BF16 if six else None,
-                'frac_of_winograd_floor': None if six or not is_wino else ach * issued / PEAK_MFMA_F32,
-                'hbm_frac_of_peak': (dbytes / dn) / (per_launch_us * 1e-6) / 1e9 / PEAK_HBM,
-                'launches_per_step': dn, 'avg_launch_us': per_launch_us,
-                'avg_launch_us_rocprof': rocprof_avg_us(kname, 512), 'rocprof_summary': ROCPROF_SUMMARY,
-                'flops_per_launch': dflops / dn, 'algorithmic_bytes_per_launch': dbytes / dn,
-                'all_conv_fwd_dgrad': {'launches_per_step': n, 'flops_per_step': fam_f, 'ms_per_step': fam_ms,
-                                       'achieved': fam_f / (fam_ms * 1e-3) / 1e12, 'frac': fam_f / (fam_ms * 1e-3) / 1e12 / PEAK_MFMA_F32},
-                'step': step_rf,
-            }
-        else:
-            gbs = dbytes / (dms * 1e-3) / 1e9
-            line['roofline'] = {
-                'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM, 'traffic': None,
-                'kernel': '%s (forward + dgrad launches of: %s)' % ('conv3x3_bf16_kernel<1, *>' if kind == 'bf16' else 'fp32 kernel', dkey), 'launches_per_step': dn,
-                'avg_launch_us': per_launch_us, 'algorithmic_bytes_per_launch': dbytes / dn,
-                'note': 'bf16 matrix-core operands, fp32 activations in HBM: algorithmic bytes are the fp32 input + output + weights',
-                'step': step_rf}
+        line['roofline'] = dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, args.dtype)
+        line['roofline']['all_conv_fwd_dgrad'] = {'launches_per_step': n, 'algorithmic_flops_per_step': fam_f, 'ms_per_step': fam_ms,
+                                                  'effective_tflops': fam_f / (fam_ms * 1e-3) / 1e12}
+        line['roofline']['step'] = step_record(step_s, args.batch, args.dtype)
     if rank == 0 and world == 1 and args.dtype == 'f32' and not args.no_bf16_line:
-        # BASELINE configs[3] per-GPU shard: same model, same batch, bf16 matrix-core operands where a bf16 kernel exists
+        # BASELINE configs[3] per-GPU shard: same model, same batch, compute_dtype bf16
         from lvae_amd import kernels as K
         model.compute_dtype = 'bf16'
         step16 = make_step()
@@ -354,23 +442,19 @@ def main():
         (k16, (n_l, f16, b16, ms16)), _, _, _, kind16 = conv_roofline(model, ring[0])
         model.compute_dtype = 'f32'
         K.set_precision('f32')
-        gbs = b16 / (ms16 * 1e-3) / 1e9
+        r16 = dominant_kernel_record(k16, n_l, f16, b16, ms16, kind16, 'bf16')
+        r16['step'] = step_record(s16, args.batch, 'bf16')
+        r16['step_hbm_frac'] = r16['step']['hbm_frac']
         line['bf16_shard'] = {
-            'config': 'BASELINE configs[3] per-GPU shard: CIFAR10 15-layer, batch %d, compute_dtype bf16 (forward, dgrad and weight gradient of the 3x3 '
-                      'convolutions of the 8x8..32x32 levels on v_mfma_f32_32x32x16_bf16, fp32 storage / accumulate / statistics / KL / '
-                      'likelihood; 1x1 and <=4x4 convolutions still fp32)' % args.batch,
+            'config': 'BASELINE configs[3] per-GPU shard: CIFAR10 15-layer, batch %d, compute_dtype bf16 (%s)' % (args.batch, K.BF16_MODE_NOTE),
             'value': args.batch / s16, 'unit': 'images/s', 'ms_per_step': s16 * 1e3, 'steps': n16, 'dtype': 'bf16',
-            'neg_elbo': -float(out16['elbo']),
-            'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM, 'traffic': None,
-                         'kernel': '%s (forward + dgrad launches of: %s)' % ('conv3x3_bf16_kernel<1, *>' if kind16 == 'bf16' else 'fp32 kernel', k16), 'launches_per_step': n_l,
-                         'avg_launch_us': ms16 * 1e3 / n_l, 'algorithmic_bytes_per_launch': b16 / n_l,
-                         'step_hbm_frac': B_ALG_PER_IMAGE * args.batch / s16 / 1e9 / PEAK_HBM}}
+            'neg_elbo': -float(out16['elbo']), 'roofline': r16}
         log('bf16 shard: %.2f ms/step' % (s16 * 1e3))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline on %d host cores ...' % host_cores())
         line['cpu_baseline'] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -13,16 +13,11 @@
  *  - every function returns 0 on success, a negative LVAE_E* code for a rejected argument, or the positive
  *    hipError_t of a failed launch. `lvae_last_error()` returns a static description of the last failure.
  *  - re-entrant. Mutable process state: the thread-local last-error string, and one atomic "dynamic-LDS attribute set" flag per
- *    kernel (an idempotent hipFuncSetAttribute on first use). Read-only process state: the tuning / A-B switches below, each read
- *    from the environment once on first use; every value selects among kernel variants that pass the same parity tests:
- *      LVAE_DISABLE_WINO, LVAE_DISABLE_WINO_WGRAD, LVAE_DISABLE_HALO, LVAE_DISABLE_W1X1   (fall back to the direct kernels)
- *      LVAE_F32_SPLIT (1: run the large fp32 3x3 layers as six exact bf16-piece products on the bf16 MFMA instead of Winograd-fp32), LVAE_DISABLE_POS, LVAE_DISABLE_GATE_FUSED, LVAE_DISABLE_BF16_WGRAD, LVAE_BF16_WGRAD_TPW, LVAE_GATE_FUSED_MIN_M,
- *      LVAE_F32_SPLIT_WGRAD (1: the same six-product form for the fp32 weight gradient of the large 3x3 layers; read per call), LVAE_F32_SPLIT_WGRAD_MIN_M,
- *      LVAE_BF16_PERSISTENT (1: persistent form of the bf16 3x3 kernel, measured slower), LVAE_DISABLE_GATE_FWD_PERSISTENT, LVAE_GATE_FWD_WGS, LVAE_GATE_FWD_MIN_M, LVAE_GATE_FWD_WT (0: dword stores straight from the accumulators), LVAE_GATE_FWD_F32_SPLIT (1: six-product form, read per call),
- *      LVAE_GATE_BWD_F32_MFMA (1: the fused gate backward on the fp32 MFMA instead of its default six-product form, read per call),
- *      LVAE_WINO_SPLIT (0: the Winograd position GEMMs of the 64-channel layers on the fp32 MFMA instead of six exact bf16-piece products on the bf16 MFMA; read per call),
- *      LVAE_WINO_WIDE (1: 256-pixel Winograd workgroups, one per CU, fp32-MFMA form only, measured slower; read per call), LVAE_F32_SPLIT_MIN_M, LVAE_WINO_MIN_M, LVAE_WINO_NARROW_TILES, LVAE_WINO_WGRAD_MIN_M, LVAE_WINO_WGRAD_MIN_CPR, LVAE_WINO_GROUP_MAX_M, LVAE_PW_BM
- *    (thresholds between variants). Phase-skip debugging switches exist only in -DLVAE_PHASE_DEBUG builds.
+ *    kernel (an idempotent hipFuncSetAttribute on first use). The library reads NO environment variable: which kernel variant runs
+ *    depends only on the descriptor — shape, alignment, `precision`, `workspace` and the `form` request below. Thresholds between
+ *    variants are compile-time constants (csrc/lvae_common.h tune(); a -DLVAE_TUNING_ENV build, used by tools/ only, can sweep them
+ *    through LVAE_* variables). Variants that were measured slower in round 2 (256-pixel Winograd workgroups, the persistent bf16 3x3
+ *    kernel, the six-product weight gradient) are no longer compiled; phase-skip switches exist only in -DLVAE_PHASE_DEBUG builds.
  *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
  *    caller owns (ladder-vae-pytorch_amd/dist.py). SURVEY.md §8(b) sketched lvae_allreduce_{init,enqueue,wait,destroy}; they
  *    would only re-wrap ncclAllReduce on a side stream, which torch.distributed already is on this platform, so the boundary
@@ -38,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 11
+#define LVAE_ABI_VERSION 12
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -47,6 +42,14 @@ extern "C" {
 /* activation ids shared by every kernel (models/lvae.py:64-69 nonlin table) */
 enum { LVAE_STATS_BN_FWD = 0, LVAE_STATS_BN_BWD = 1 };
 enum { LVAE_PREC_F32 = 0, LVAE_PREC_BF16 = 1 };
+/* lvae_conv_desc.form: which arithmetic form an fp32 (LVAE_PREC_F32) descriptor asks for. All forms pass the same parity tests. */
+enum {
+  LVAE_FORM_AUTO = 0,               /* the library's choice for the shape (what the training step uses) */
+  LVAE_FORM_F32_MFMA = 1,           /* every matrix product on v_mfma_f32_32x32x2_f32: Winograd / gate backward without the six-product form */
+  LVAE_FORM_SIX_PRODUCT = 2,        /* six exact bf16-piece products per fp32 product wherever the selected kernel has that form (adds the
+                                       GateLayer2d forward, which is HBM-bound and defaults to the fp32 MFMA) */
+  LVAE_FORM_SIX_PRODUCT_DIRECT = 3  /* large 3x3 layers as a DIRECT six-product convolution instead of Winograd (measured: ties at 16x16, loses at 32x32) */
+};
 enum { LVAE_ACT_NONE = 0, LVAE_ACT_ELU = 1, LVAE_ACT_RELU = 2, LVAE_ACT_LEAKYRELU = 3, LVAE_ACT_SELU = 4 };
 
 /* spatial gather of an implicit-GEMM convolution */
@@ -124,6 +127,7 @@ typedef struct lvae_conv_desc {
   const float* stats_x;
   /* Folded BatchNorm finalize of the INPUT: NULL, or a HOST pointer to the block below (read by the launcher, not by the device) */
   const struct lvae_bn_fold* in_fold;
+  int32_t form;           /* LVAE_FORM_* (0 = LVAE_FORM_AUTO) */
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -131,6 +135,17 @@ typedef struct lvae_conv_desc {
  * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
 size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+/* Which kernel family lvae_conv2d_f32 runs for `d` as given (workspace and form included): diagnostics for the parity tests and for
+ * bench.py's roofline record (which matrix unit issues the FLOPs). */
+enum {
+  LVAE_VARIANT_DIRECT = 0,       /* fp32 MFMA, direct: halo-tile 3x3, single-shot 1x1 or the generic implicit GEMM */
+  LVAE_VARIANT_POS = 2,          /* position-major 3x3 of the <= 4x4 levels (fp32 MFMA) */
+  LVAE_VARIANT_WINO_F32 = 3,     /* Winograd F(2x2,3x3), position GEMMs on the fp32 MFMA */
+  LVAE_VARIANT_WINO_SIX = 4,     /* Winograd F(2x2,3x3), position GEMMs as six bf16-piece products on the bf16 MFMA */
+  LVAE_VARIANT_BF16_DIRECT = 5,  /* direct 3x3, bf16 operands on the bf16 MFMA (precision LVAE_PREC_BF16) */
+  LVAE_VARIANT_SIX_DIRECT = 6    /* direct 3x3, six-product form (form LVAE_FORM_SIX_PRODUCT_DIRECT) */
+};
+int32_t lvae_conv2d_variant(const lvae_conv_desc* d);
 /* The same convolution with bf16 matrix-core operands (v_mfma_f32_32x32x16_bf16): activations (after the fused input transform)
  * and weights are rounded to bf16, products are exact, accumulation, bias, statistics and the stored result are fp32 — the
  * arithmetic of the reference's nn.Conv2d call sites under torch.autocast(bfloat16) (BASELINE configs[1], [3], [4]). Equivalent to

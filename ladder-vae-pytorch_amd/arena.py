@@ -14,7 +14,7 @@ Within the trainable prefix the parameters are laid out by GRADIENT-COMPLETION O
 `grad_segments()`, i.e. reverse execution order: likelihood head, final top-down blocks, top-down layers 0..L-1, bottom-up
 layers L-1..0, stem) — not by registration order (models/lvae.py:74,87-88,156,159-167 of the reference registers bottom-up and
 top-down layers interleaved). A data-parallel bucket is then a contiguous slice of the gradient arena that is complete as soon
-as backward has left its last segment (`segments` = [(lo, hi)] in that order), so its all-reduce can start while backward
+as backward has left its last segment (`segments` = [(segment id, lo, hi)] in that order), so its all-reduce can start while backward
 continues (dist.GradAllReduce). The state_dict order is untouched (it follows module registration).
 """
 import torch
@@ -49,12 +49,14 @@ class ParamArena:
         self.params = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=device)
         self.slots = {}
-        self.segments = []          # [(lo, hi)] element ranges of the gradient arena, one per segment, in completion order
+        # [(segment id, lo, hi)]: element ranges of the gradient arena in completion order; the id is what the model's segment
+        # markers report (a segment that owns no trainable parameter has no entry here, so ids may have gaps)
+        self.segments = []
         lo = 0
         for i, sz in enumerate(sizes[:len(train)]):
             if i + 1 == len(train) or seg_ids[i + 1] != seg_ids[i]:
                 hi = sum(sizes[:i + 1])
-                self.segments.append((lo, hi))
+                self.segments.append((seg_ids[i], lo, hi))
                 lo = hi
         off = 0
         for (k, p), sz in zip(train + frozen, sizes):

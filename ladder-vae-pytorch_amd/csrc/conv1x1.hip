@@ -286,7 +286,7 @@ static int launch_pw(const PwArgs& a, hipStream_t s) {
 
 template <int KT, int NT, bool KC>
 static int pick_bm(const PwArgs& a, hipStream_t s) {
-  static const int force = getenv("LVAE_PW_BM") ? atoi(getenv("LVAE_PW_BM")) : 0;  // tuning switch
+  static const int force = (int)tune("LVAE_PW_BM", 0);
   if (force == 64) return launch_pw<64, KT, NT, KC>(a, s);
   if (force == 128) return launch_pw<128, KT, NT, KC>(a, s);
   return launch_pw<64, KT, NT, KC>(a, s);  // measured: 64-pixel tiles (2-3 workgroups per CU overlap load / MFMA / store) beat 128

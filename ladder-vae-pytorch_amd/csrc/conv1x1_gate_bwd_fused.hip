@@ -371,12 +371,12 @@ static int gbf_nwg(int64_t M) {
 // `d` describes the dgrad of the gate convolution exactly as for lvae_conv1x1_gate_bwd_f32 (C1 = 2C = 128, Cout = C = 64, weight
 // strides of the transposed view, y = dx, out_scale = dropout mask). 0 when this kernel does not take the shape.
 size_t conv1x1_gate_bwd_fused_workspace(const lvae_conv_desc* d) {
-  static const bool off = getenv("LVAE_DISABLE_GATE_FUSED") != nullptr;  // A/B switch, profiling only
+  static const bool off = tune("LVAE_DISABLE_GATE_FUSED", 0) != 0;  // A/B switch (tuning builds only)
   if (off || d == nullptr) return 0;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W) return 0;
   if (d->C1 != 128 || d->C2 != 0 || d->Cout != 64 || d->w_sk != 1 || d->w_sn % 4 != 0 || d->in_scale != nullptr) return 0;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  static const int64_t min_m = getenv("LVAE_GATE_FUSED_MIN_M") ? atoll(getenv("LVAE_GATE_FUSED_MIN_M")) : 256 * 64;  // tuning switch
+  static const int64_t min_m = tune("LVAE_GATE_FUSED_MIN_M", 256 * 64);
   if (M < min_m || M >= ((int64_t)1 << 31)) return 0;
   return (size_t)gbf_nwg(M) * (64 * 128 + 128) * sizeof(float);
 }
@@ -410,8 +410,7 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     }
     attr_set = true;
   }
-  const char* f32sw = getenv("LVAE_GATE_BWD_F32_MFMA");  // A/B switch, read per call (the parity tests run both fp32 forms in one process)
-  const bool f32_mfma = f32sw != nullptr && atoi(f32sw) != 0;
+  const bool f32_mfma = d->form == LVAE_FORM_F32_MFMA;  // default for fp32: the six-product form on the bf16 MFMA
   if (d->precision == LVAE_PREC_BF16) {
     hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel<1>, dim3(nwg), dim3(512), gbb_lds(1), s, a);
   } else if (!f32_mfma) {

@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
 
 // workgroups the persistent kernel runs for this descriptor (== rows of BatchNorm partials it writes); 0: not this kernel
 int conv1x1_gate_fwd_wgs(const lvae_conv_desc* d) {
-  static const bool off = getenv("LVAE_DISABLE_GATE_FWD_PERSISTENT") != nullptr;  // A/B switch, profiling only
-  static const int max_wgs = getenv("LVAE_GATE_FWD_WGS") ? atoi(getenv("LVAE_GATE_FWD_WGS")) : 512;  // tuning switch
-  static const int64_t min_m = getenv("LVAE_GATE_FWD_MIN_M") ? atoll(getenv("LVAE_GATE_FWD_MIN_M")) : 0;  // tuning switch
+  static const bool off = tune("LVAE_DISABLE_GATE_FWD_PERSISTENT", 0) != 0;  // A/B switch (tuning builds only)
+  static const int max_wgs = (int)tune("LVAE_GATE_FWD_WGS", 512);
+  static const int64_t min_m = tune("LVAE_GATE_FWD_MIN_M", 0);
   if (off || d == nullptr) return 0;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W || d->gather != LVAE_GATHER_CONV) return 0;
   if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->Cout != 128) return 0;
@@ -313,11 +313,11 @@ int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, 
   a.M = (int)((int64_t)d->N * d->H * d->W);
   a.tiles = (a.M + GF_BM - 1) / GF_BM;
   a.act = act;
-  static const bool wt = getenv("LVAE_GATE_FWD_WT") == nullptr || atoi(getenv("LVAE_GATE_FWD_WT")) != 0;  // A/B switch, profiling only
+  static const bool wt = tune("LVAE_GATE_FWD_WT", 1) != 0;  // A/B switch (tuning builds only)
   const bool al = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d->y) |
                     reinterpret_cast<uintptr_t>(d->stats_pivot)) & 15) == 0;
-  const char* f32sw = getenv("LVAE_GATE_FWD_F32_SPLIT");  // A/B switch, read per call (the parity tests run both fp32 forms in one process)
-  const int split = d->precision == LVAE_PREC_BF16 ? 1 : ((f32sw != nullptr && atoi(f32sw) != 0) ? 3 : 0);
+  // fp32: on the fp32 MFMA by default (the kernel is HBM-bound: the six-product form measured the same); d->form = LVAE_FORM_SIX_PRODUCT asks for it
+  const int split = d->precision == LVAE_PREC_BF16 ? 1 : (d->form == LVAE_FORM_SIX_PRODUCT ? 3 : 0);
   const dim3 grid(wgs), block(256);
   if (wt && al) {
     if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1>), grid, block, 0, s, a);

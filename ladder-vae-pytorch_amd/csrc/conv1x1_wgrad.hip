@@ -126,7 +126,7 @@ void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, i
                          int64_t sk, int64_t sn, float* dw, float* db, hipStream_t s);
 
 static bool w1x1_plan(const lvae_conv_desc* d, int& nwg, int& ppw) {
-  static const bool off = getenv("LVAE_DISABLE_W1X1") != nullptr;  // A/B switch, profiling only
+  static const bool off = tune("LVAE_DISABLE_W1X1", 0) != 0;  // A/B switch (tuning builds only)
   if (off) return false;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->gather != LVAE_GATHER_CONV) return false;
   if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->in_scale != nullptr) return false;

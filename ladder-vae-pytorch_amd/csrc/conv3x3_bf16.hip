@@ -264,189 +264,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// bf16 operands (SPLIT = 1), persistent form. With bf16 MFMAs the arithmetic of a tile is ~1 us; what a launch costs is the HBM
-// round trip of its patch and the write of its outputs. In the one-tile-per-workgroup form above every workgroup of a layer is
-// resident at once, so all of them read, then compute, then write together (20 us at 256x16x16 against a 5.6 us HBM floor). Here two
-// workgroups per CU loop over tiles: the raw patch of the NEXT tile is fetched into registers while the current tile's MFMAs and
-// stores run, so reads and writes of different tiles overlap and the memory system stays busy.
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int MI>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16p_kernel(BfArgs a) {
-  constexpr int BM = 64 * MI, LDK = BF_LDK, NV = 13;  // NV: float4 of a patch per thread (halo_px <= 208 checked on the host)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);   // [halo_px][LDK]
-  const lvae_conv_desc& d = a.d;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int Cin = a.Cin;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int tiles_m = ((d.N + a.NI - 1) / a.NI) * a.tiles_h, total_tiles = tiles_m * a.ntn;
-  const int tile_px = a.NI * a.TH * a.TW, per_img = a.halo_h * a.halo_w;
-
-  const int c4 = (t & 15) * 4, px0 = t >> 4;
-  const bool c_ok = c4 < Cin;
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
-  if (d.in_scale && c_ok) {
-    sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
-    sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
-  }
-  f32x4 hv[NV];
-  unsigned hok = 0;
-  auto prefetch = [&](int tile) {
-    const int tm = tile / a.ntn, ig = fastdiv(tm, a.m_tiles_h), th_idx = tm - ig * a.tiles_h;
-    const int n0 = ig * a.NI, oh0 = th_idx * a.TH;
-    hok = 0;
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int px = px0 + 16 * u;
-      const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
-      const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
-      const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
-      const bool ok = (px < a.halo_px) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & c_ok;
-      const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin) : 0u;
-      hv[u] = *reinterpret_cast<const f32x4*>(d.x + c4 + off);
-      hok |= ok ? (1u << u) : 0u;
-    }
-  };
-
-  int hbase[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    int p = wm * (32 * MI) + mi * 32 + li;
-    if (p >= tile_px) p = 0;
-    const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
-    const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
-    hbase[mi] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDK + 8 * lh;
-  }
-
-  int tile = blockIdx.x;
-  if (tile < total_tiles) prefetch(tile);
-  for (; tile < total_tiles; tile += gridDim.x) {
-    const int tile_n = tile % a.ntn, tm = tile / a.ntn;
-    const int ig = fastdiv(tm, a.m_tiles_h), th_idx = tm - ig * a.tiles_h;
-    const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * 64;
-    // ---- weights of this tile's output channels: B fragments straight from L2, two k-steps ahead
-    bf16x8 bq[3];
-    const __bf16* wp_lane = a.Wp + (size_t)tile_n * 4 * 1024 + (size_t)wn * 512 + (size_t)lane * 8;
-    auto load_b = [&](int step) {
-      const int tap = step >> 2, ks = step & 3;
-      return *reinterpret_cast<const bf16x8*>(wp_lane + ((size_t)(tap * a.ntn) * 4 + ks) * 1024);
-    };
-    bq[0] = load_b(0);
-    bq[1] = load_b(1);
-    // ---- registers -> LDS patch (transform, round to bf16); pixels outside the image / batch are zero
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int px = px0 + 16 * u;
-      if (px < a.halo_px) {
-        f32x4 w = zero4;
-        if ((hok >> u) & 1u) {
-          w = hv[u];
-          if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
-        }
-        bf16x4 pl[1];
-        split4<1>(w, pl);
-        *reinterpret_cast<bf16x4*>(As + px * LDK + c4) = pl[0];
-      }
-    }
-    __syncthreads();
-    if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);  // in flight during the MFMAs and the stores below
-
-    f32x16 acc[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-    bf16x8 af[2][MI];
-    auto load_a = [&](int step, bf16x8 (&fa)[MI]) {
-      const int tap = step >> 2, ks = step & 3;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
-      const int off = (dh * a.halo_w + dw) * LDK + ks * 16;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(As + hbase[mi] + off);
-    };
-    load_a(0, af[0]);
-#pragma unroll
-    for (int step = 0; step < 36; ++step) {
-      const int cur = step & 1;
-      if (step + 2 < 36) bq[(step + 2) % 3] = load_b(step + 2);
-      if (step + 1 < 36) load_a(step + 1, af[cur ^ 1]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mi], bq[step % 3], acc[mi], 0, 0, 0);
-    }
-    __syncthreads();  // every wave is done with the patch: LDS becomes the output staging tile
-
-    constexpr int LDO = 68;
-    float* Os = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Os[(wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
-    __syncthreads();
-    const int col = co0 + c4;
-    f32x4 st1 = zero4, st2 = zero4, piv = zero4;
-    if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
-    f32x4 bsh = piv, bmu = piv, brs = piv;
-    if (d.stats_out && d.stats_mode == LVAE_STATS_BN_BWD && col < d.Cout) {
-      bsh = *reinterpret_cast<const f32x4*>(d.stats_pivot + d.Cout + col);
-      bmu = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col);
-      brs = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col);
-    }
-    if (col < d.Cout) {
-      f32x4 bias = zero4;
-      if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
-      float* yp = d.y + ((size_t)(n0 * d.H + oh0) * d.W + px0) * d.Cout + col;
-      const float* op = Os + px0 * LDO + c4;
-      const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
-#pragma unroll
-      for (int q = 0; q < BM / 16; ++q) {
-        const int p = px0 + 16 * q;
-        if (p < nvalid) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias;
-          if (d.out_scale) {
-            const int n = n0 + fastdiv(p, a.m_thw);
-            v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
-          }
-          v = act_fwd4(v, d.out_act);
-          store_wt4(yp + (size_t)q * 16 * d.Cout, v);
-          if (d.stats_mode == LVAE_STATS_BN_BWD) {
-            if (d.stats_out) {
-              const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
-                st1[j] += gj;
-                st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
-              }
-            }
-          } else {
-            const f32x4 dl = v - piv;
-            st1 += dl;
-            st2 += dl * dl;
-          }
-        }
-      }
-    }
-    __syncthreads();  // the staging tile is read
-    if (d.stats_out) {
-      float* red = reinterpret_cast<float*>(smem_raw);
-      *reinterpret_cast<f32x4*>(red + px0 * 64 + c4) = st1;
-      *reinterpret_cast<f32x4*>(red + 1024 + px0 * 64 + c4) = st2;
-      __syncthreads();
-      if (t < 128) {
-        const int c = t & 63, which = t >> 6;
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v += red[which * 1024 + r * 64 + c];
-        if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
-      }
-      __syncthreads();
-    }
-  }
-}
+// (A persistent two-workgroups-per-CU form of this kernel, prefetching the next tile's patch during the MFMAs, was built in round 2 and
+// measured slower on the CIFAR-15 step, 33.8 vs 33.1 ms: at 256x16x16 there is one tile per workgroup anyway. Removed.)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Weight gradient with bf16 operands:  dW[tap][ci][co] += sum_pixels T(x)[pixel + tap][ci] * dy[pixel][co],  db[co] += sum dy
@@ -765,16 +584,15 @@ bool conv3x3_bf16_eligible(const lvae_conv_desc* d, int split) {
 }
 
 // Which bf16-matrix-pipe form a 3x3 descriptor takes: 1 = bf16 operands (precision LVAE_PREC_BF16), 3 = the fp32-equivalent
-// six-product split for the large fp32 layers (LVAE_F32_SPLIT=0 keeps them on the fp32 MFMA / Winograd kernels), 0 = neither.
+// six-product split for the large fp32 layers (form = LVAE_FORM_SIX_PRODUCT_DIRECT only), 0 = neither.
 int conv3x3_bf16_form(const lvae_conv_desc* d) {
   if (d->precision == LVAE_PREC_BF16) return conv3x3_bf16_eligible(d, 1) ? 1 : 0;
   // Off by default: measured on MI355X (profiles/r02_conv3x3_forms.txt) the six-product form only ties Winograd-fp32 at 16x16
   // (32.3 vs 31.1 us) and loses at 32x32 (122 vs 100 us): under a dense bf16-MFMA load the chip holds ~1.6 GHz, so 6/16 of the
-  // fp32-MFMA cycles is worth ~280 TFLOP/s fp32-equivalent against Winograd's 16/36 on the fp32 pipe. Read per call (the parity
-  // tests run both forms in one process).
-  const char* sw = getenv("LVAE_F32_SPLIT");
-  const bool split_on = sw != nullptr && atoi(sw) != 0;
-  static const int64_t min_m = getenv("LVAE_F32_SPLIT_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_MIN_M")) : 256 * 64;  // tuning switch
+  // fp32-MFMA cycles is worth ~280 TFLOP/s fp32-equivalent against Winograd's 16/36 on the fp32 pipe. Only when the descriptor
+  // asks for it (form = LVAE_FORM_SIX_PRODUCT_DIRECT; the parity tests do).
+  const bool split_on = d->form == LVAE_FORM_SIX_PRODUCT_DIRECT;
+  static const int64_t min_m = tune("LVAE_F32_SPLIT_MIN_M", 256 * 64);
   if (!split_on || (int64_t)d->N * d->H * d->W < min_m) return 0;
   return conv3x3_bf16_eligible(d, 3) ? 3 : 0;
 }
@@ -821,20 +639,7 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
   static const int dbg = lvae::debug_phase_switch("LVAE_BF16_DEBUG");  // phase-skip builds (-DLVAE_PHASE_DEBUG) only; 0 in the product
   a.debug = dbg;
   a.ntn = (d->Cout + 63) / 64;
-  // measured (CIFAR-15 step, bf16): the persistent form is SLOWER (33.8 vs 33.1 ms/step) — at 256x16x16 there is one tile per
-  // workgroup anyway and at 32x32 the per-tile latency chain, not the overlap, is what counts; kept behind LVAE_BF16_PERSISTENT=1
-  static const bool persistent = getenv("LVAE_BF16_PERSISTENT") != nullptr && atoi(getenv("LVAE_BF16_PERSISTENT")) != 0;  // A/B switch
-  if (split == 1 && persistent && a.halo_px <= 208) {
-    const int total_tiles = ((d->N + a.NI - 1) / a.NI) * a.tiles_h * a.ntn;
-    const int grid = total_tiles < 512 ? total_tiles : 512;   // two workgroups per CU
-    a.m_tiles_h = fastdiv_magic(a.tiles_h);
-    a.d.in_fold = nullptr;
-    const size_t lds = bf_lds_bytes(1, a.halo_px, a.bm);
-    if (a.bm == 128) hipLaunchKernelGGL(conv3x3_bf16p_kernel<2>, dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(conv3x3_bf16p_kernel<1>, dim3(grid), dim3(256), lds, s, a);
-    LVAE_LAUNCH_CHECK("conv3x3_bf16p");
-    return 0;
-  }
+  // (a persistent form of this kernel was built in round 2 and measured slower, 33.8 vs 33.1 ms/step: removed)
   if (split == 1) {
     const int64_t wgs = (int64_t)((d->N + a.NI - 1) / a.NI) * a.tiles_h * a.ntn;
     const bool pre = wgs <= 512;  // one round of two workgroups per CU (measured: 16x16 19.9 -> 18.0 us, 8x8 13.8 -> 9.8; 32x32 53 -> 65 with it)
@@ -845,18 +650,12 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
 }
 
 // ---- bf16 weight gradient: host side
-// 0: not this kernel; 1: bf16 operands (precision LVAE_PREC_BF16); 3: fp32-equivalent six-product split for precision LVAE_PREC_F32,
-// only with LVAE_F32_SPLIT_WGRAD=1 and on layers of at least 32768 pixels. Measured on the CIFAR-15 step: 39.5 ms with it against 37.9 ms
-// with the Winograd-domain fp32 kernel (the six-fold matrix work is not hidden behind the slab traffic because staging and MFMAs alternate
-// on one LDS buffer), so the default keeps every fp32 gradient on the fp32 MFMA; the parity tests run both forms.
+// 0: not this kernel; 1: bf16 operands (precision LVAE_PREC_BF16). (The fp32-equivalent six-product form of this kernel, SPLIT = 3, was
+// built in round 2 and measured slower than the Winograd-domain fp32 kernel, 39.5 vs 37.9 ms/step: no longer instantiated.)
 static int bfwg_form(const lvae_conv_desc* d) {
-  static const bool off = getenv("LVAE_DISABLE_BF16_WGRAD") != nullptr;  // A/B switch, profiling only
+  static const bool off = tune("LVAE_DISABLE_BF16_WGRAD", 0) != 0;  // A/B switch (tuning builds only)
   if (off) return 0;
-  if (d->precision == LVAE_PREC_BF16) return 1;
-  const char* sw = getenv("LVAE_F32_SPLIT_WGRAD");  // A/B switch, read per call (the parity tests run both forms in one process)
-  if (sw == nullptr || atoi(sw) == 0) return 0;
-  static const int64_t min_m = getenv("LVAE_F32_SPLIT_WGRAD_MIN_M") ? atoll(getenv("LVAE_F32_SPLIT_WGRAD_MIN_M")) : 32768;  // tuning switch
-  return (int64_t)d->N * d->H * d->W >= min_m ? 3 : 0;
+  return d->precision == LVAE_PREC_BF16 ? 1 : 0;
 }
 
 static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
@@ -888,7 +687,7 @@ static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
 // workgroups = split-K ranges = partial slabs (147 KB each for 64 -> 64): the slab write + reduce traffic, not the MFMAs, is what this
 // kernel costs; measured on the CIFAR-15 step (bf16 mode): 2 tiles per workgroup 33.3 ms, 4 -> 33.7, 8 -> 36.1
 static int bfwg_nwg(const BfWgArgs& a) {
-  static const int tpw = getenv("LVAE_BF16_WGRAD_TPW") ? atoi(getenv("LVAE_BF16_WGRAD_TPW")) : 2;  // tuning switch
+  static const int tpw = (int)tune("LVAE_BF16_WGRAD_TPW", 2);
   int n = (a.ntiles + tpw - 1) / tpw;
   if (n > 256) n = 256;
   if (n < 1) n = 1;
@@ -917,23 +716,8 @@ int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, 
   size_t lds = (size_t)a.split * (a.halo_px + a.bm) * BF_LDK * 2;
   if (lds < 32 * 64 * 4) lds = 32 * 64 * 4;
   const dim3 grid(nwg, (d->Cout + 63) / 64);
-  static std::atomic<bool> attr_set{false};  // idempotent attribute writes; the flag itself is race-free
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("conv3x3_wgrad_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-    attr_set = true;
-  }
-  if (a.split == 1) {
-    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1>), grid, dim3(512), lds, s, a);
-  } else {
-    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 3>), grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 3>), grid, dim3(512), lds, s, a);
-  }
+  if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1>), grid, dim3(512), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16");
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 9, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
   LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16_reduce");

@@ -284,7 +284,7 @@ static bool al16q(const void* p) { return p == nullptr || (reinterpret_cast<uint
 
 // eligibility: 3x3 / stride 1 / pad 1 on images of at most 16 pixels, 32 or 64 reduction channels
 static bool pos_select(const lvae_conv_desc* d, bool& ncontig) {
-  static const bool off = getenv("LVAE_DISABLE_POS") != nullptr;  // A/B switch, profiling only
+  static const bool off = tune("LVAE_DISABLE_POS", 0) != 0;  // A/B switch (tuning builds only)
   if (off) return false;
   const int Cin = d->C1;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;

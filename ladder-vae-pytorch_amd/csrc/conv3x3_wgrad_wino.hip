@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(Wi
 static bool al16g(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static bool wg_wino_plan(const lvae_conv_desc* d, WgWinoArgs& a) {
-  static const bool off = getenv("LVAE_DISABLE_WINO_WGRAD") != nullptr || getenv("LVAE_DISABLE_WINO") != nullptr;  // A/B switch
+  static const bool off = tune("LVAE_DISABLE_WINO_WGRAD", 0) != 0 || tune("LVAE_DISABLE_WINO", 0) != 0;  // A/B switch (tuning builds only)
   if (off) return false;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->gather != LVAE_GATHER_CONV) return false;
   if (d->C1 != 64 || d->C2 != 0 || d->x2 != nullptr || d->Cout % 4 != 0 || d->Cout > 256) return false;
@@ -165,14 +165,14 @@ static bool wg_wino_plan(const lvae_conv_desc* d, WgWinoArgs& a) {
   if ((d->H / 2) % tr != 0) return false;
   if (!al16g(d->x) || !al16g(d->in_scale) || !al16g(d->in_shift)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  static const int64_t min_m = getenv("LVAE_WINO_WGRAD_MIN_M") ? atoll(getenv("LVAE_WINO_WGRAD_MIN_M")) : 256 * 64;  // tuning switch
+  static const int64_t min_m = tune("LVAE_WINO_WGRAD_MIN_M", 256 * 64);
   if (M < min_m || M * 256 >= ((int64_t)1 << 31)) return false;
   a.ncog = (d->Cout + 63) / 64;
   a.cpi = (d->H / 2) / tr;
   a.total_chunks = d->N * a.cpi;
   int nranges = 128 / a.ncog;  // 256 workgroups with the two input-channel blocks
   if (nranges < 1) nranges = 1;
-  static const int min_cpr = getenv("LVAE_WINO_WGRAD_MIN_CPR") ? atoi(getenv("LVAE_WINO_WGRAD_MIN_CPR")) : 4;  // tuning switch
+  static const int min_cpr = (int)tune("LVAE_WINO_WGRAD_MIN_CPR", 4);
   if (nranges > a.total_chunks / min_cpr) nranges = a.total_chunks / min_cpr;  // slab traffic: at least min_cpr chunks per slab
   if (nranges < 1) nranges = 1;
   a.cpr = (a.total_chunks + nranges - 1) / nranges;

@@ -32,6 +32,7 @@ struct WinoArgs {
   const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3; six-product form: bf16 [16][4 k16][Npad/32][3 pieces][64 lanes][8]
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, Cin;
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
+  int debug;  // phase-skip bits, -DLVAE_PHASE_DEBUG builds only (tools/wino_phase.sh); always 0 in the product
 };
 
 // Six-product form (conv3x3_wino_kernel<.., SPL = true>): U[p][k][n] split exactly into three bf16 pieces, stored in the B-fragment order of
@@ -154,7 +155,7 @@ constexpr int WLDO = 68;  // R row stride (floats)
 // of a wave, and — one wave per SIMD, nothing else to hide an L2 round trip — keeps its U fragments three k-steps ahead in a
 // register ring pinned with sched_barrier.
 // MT: 32-tile row blocks per wave. 1 = the layout described above (128 output pixels per workgroup, two workgroups per CU).
-// 2 (LVAE_WINO_WIDE=1, an experiment that is parity-tested but NOT the default) = 256 output pixels per workgroup, ONE workgroup per CU,
+// 2 (a round-2 experiment, no longer instantiated) = 256 output pixels per workgroup, ONE workgroup per CU,
 // one wave per SIMD with the whole 512-entry register file (sixteen 32x32 accumulators per wave, in AGPRs): every U fragment a wave
 // fetches from L2 feeds two MFMAs instead of one (the U stream is 262 KB per workgroup whatever its tile) and a 16x16 level at batch
 // 256 is exactly one image per CU. Measured: 46.2 us against 33.6 us at 256x16x16, 165 against 122 us at 32x32 (step 40.3 vs 37.1 ms).
@@ -184,6 +185,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
+#ifdef LVAE_PHASE_DEBUG
+  const int dbg = a.debug;  // 1: no halo loads, 2: no transform/split/MFMA, 4: no output stores, 8: U from one hot KB, 16: no epilogue at all, 32: no split (MFMAs on raw bits)
+#else
+  constexpr int dbg = 0;
+#endif
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
     for (int u = 0; u < SLOTS; ++u) {
       const bool live = hoff[u] != ~0u && 16 * c + hc4 < a.Cin;  // channels beyond Cin (CIN padding) read as zero
       const unsigned off = live ? hoff[u] + 16 * c : 0u;
-      hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      if (dbg & 1) hreg[u] = zero4;
+      else hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
       hlive = live ? hlive | (1u << u) : hlive & ~(1u << u);
     }
   };
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
     constexpr int BR = 3;
     bf16x8 bq[BR][NH][3];
     auto load_b = [&](int it, int buf) {  // it = 4 s + j
-      const __bf16* p = u3 + (size_t)((4 * wave + (it & 3)) * 4 + (it >> 2)) * NB * 1536;
+      const __bf16* p = u3 + ((dbg & 8) ? (size_t)0 : (size_t)((4 * wave + (it & 3)) * 4 + (it >> 2)) * NB * 1536);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 #pragma unroll
     for (int s16 = 0; s16 < NSLICE; ++s16) {
       f32x4 tl[4], th[4];  // t = d[ra] + sgn * d[rb] for the four pixel columns, channels 16 s + 8 lh + {0..3 | 4..7}
+      if (!(dbg & 2)) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const f32x4 dal = *reinterpret_cast<const f32x4*>(pa[0] + c * WLDA + s16 * 16);
@@ -365,16 +373,33 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
         const f32x4 vl = j == 0 ? tl[0] - tl[2] : (j == 1 ? tl[1] + tl[2] : (j == 2 ? tl[2] - tl[1] : tl[1] - tl[3]));
         const f32x4 vh = j == 0 ? th[0] - th[2] : (j == 1 ? th[1] + th[2] : (j == 2 ? th[2] - th[1] : th[1] - th[3]));
         bf16x4 pl[3], ph[3];
+        bf16x8 af[3];
+        if (dbg & 32) {
+          af[0] = __builtin_bit_cast(bf16x8, vl);
+          af[1] = __builtin_bit_cast(bf16x8, vh);
+          af[2] = __builtin_bit_cast(bf16x8, vl + vh);
+        } else {
         split4<3>(vl, pl);
         split4<3>(vh, ph);
-        bf16x8 af[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) af[q] = bf16x8{pl[q][0], pl[q][1], pl[q][2], pl[q][3], ph[q][0], ph[q][1], ph[q][2], ph[q][3]};
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
           for (int k = 0; k < 6; ++k)
             acc[0][j][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bq[it % BR][h][PB[k]], acc[0][j][h], 0, 0, 0);
+      }
+      } else {  // dbg & 2: keep the U stream alive, nothing else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int it = 4 * s16 + j;
+          if (BR < 4 * NSLICE && it + BR - 1 < 4 * NSLICE) load_b(it + BR - 1, (it + BR - 1) % BR);
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[0][j][h][q] += (float)bq[it % BR][h][q][0];
+        }
       }
       if (s16 < NSLICE - 1) {  // publish the next 16-channel slice, start fetching the one after
         store_slice(s16 + 1);
@@ -384,6 +409,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
     }
   }
   __syncthreads();  // every wave is done with the halo patch: LDS becomes R[wave][b][tile][co]
+  if (dbg & 16) {
+    if (acc[0][0][0][0] + acc[0][1][0][1] + acc[0][2][NH - 1][2] + acc[0][3][NH - 1][3] == 12345.678f) d.y[t] = 1.f;
+    return;
+  }
 
   // ---- R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]; accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh
   float* Rs = smem;  // R[wave i][b][NT tiles][WLDO]
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
           v = v + bias;
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
-          store_wt4(yb + (size_t)p * d.Cout, v);
+          if (!(dbg & 4) || v[0] == 12345.678f) store_wt4(yb + (size_t)p * d.Cout, v);
           if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
@@ -487,17 +516,15 @@ static bool wino_tile_for(const lvae_conv_desc* d, int budget, int max_halo, int
 
 // layers with fewer pixel tiles than CUs run 32-channel workgroups (conv3x3_wino_kernel<64, 1, 1, false>)
 static bool wino_narrow(const lvae_conv_desc* d, int TH, int NI) {
-  static const int narrow_tiles = getenv("LVAE_WINO_NARROW_TILES") ? atoi(getenv("LVAE_WINO_NARROW_TILES")) : 256;  // tuning switch
+  static const int narrow_tiles = (int)tune("LVAE_WINO_NARROW_TILES", 256);
   return kpad_is64(d) && ((d->N + NI - 1) / NI) * (d->H / TH) < narrow_tiles;
 }
 
 // six-product form (conv3x3_wino_kernel<64, 2, 1, true>): fp32 precision, 64 reduction channels, at least 256 pixel tiles (the
 // 32-channel workgroups of smaller layers are latency chains, one wave per SIMD: 17.5 us in this form against 16.4 us on the fp32 MFMA);
-// LVAE_WINO_SPLIT=0 keeps the fp32 MFMA everywhere (read per call: the parity tests run both forms in one process)
+// d->form = LVAE_FORM_F32_MFMA keeps the position GEMMs on the fp32 MFMA
 static bool wino_split_form(const lvae_conv_desc* d) {
-  if (d->precision != LVAE_PREC_F32 || !kpad_is64(d)) return false;
-  const char* sw = getenv("LVAE_WINO_SPLIT");
-  if (sw != nullptr && atoi(sw) == 0) return false;
+  if (d->precision != LVAE_PREC_F32 || !kpad_is64(d) || d->form == LVAE_FORM_F32_MFMA) return false;
   int TH, NI;
   return wino_tile_for(d, 128, 256, TH, NI) && !wino_narrow(d, TH, NI);
 }
@@ -509,39 +536,37 @@ size_t conv3x3_wino_workspace(const lvae_conv_desc* d) {
 }
 
 bool conv3x3_wino_eligible(const lvae_conv_desc* d) {
-  static const bool off = getenv("LVAE_DISABLE_WINO") != nullptr;  // A/B switch, profiling only
+  static const bool off = tune("LVAE_DISABLE_WINO", 0) != 0;  // A/B switch (tuning builds only)
   if (off) return false;
   const int Cin = d->C1;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->x2 != nullptr || d->OH != d->H || d->OW != d->W) return false;
   if (Cin < 36 || Cin > 128 || Cin % 4 != 0 || d->Cout % 4 != 0 || (d->H & 1) || (d->W & 1) || d->W > 128) return false;
   if (!al16w2(d->x) || !al16w2(d->y) || !al16w2(d->bias) || !al16w2(d->in_scale) || !al16w2(d->in_shift) || !al16w2(d->out_scale)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
-  static const int64_t min_m = getenv("LVAE_WINO_MIN_M") ? atoll(getenv("LVAE_WINO_MIN_M")) : 256 * 64;  // tuning switch
+  static const int64_t min_m = tune("LVAE_WINO_MIN_M", 256 * 64);
   if (M < min_m || M * 128 >= ((int64_t)1 << 31)) return false;  // large layers only: smaller ones are latency bound
   return true;
 }
 
-// Pixel tile of a workgroup: whole rows, even height, <= 128 * mt pixels (32 * mt Winograd tiles); whole images when several fit.
-// mt = 2 (256 pixels, one workgroup per CU, conv3x3_wino_kernel<64, 2, 2>) only with LVAE_WINO_WIDE=1, when the layer reduces over
-// <= 64 channels and such a grid still has at least 256 workgroups; otherwise mt = 1.
+// Pixel tile of a workgroup: whole rows, even height, <= 128 pixels (32 Winograd tiles); whole images when several fit. (A 256-pixel,
+// one-workgroup-per-CU form, MT = 2, was built and measured in round 2: 46.2 us against 33.6 us at 256x16x16; it is no longer compiled.)
 struct WinoTile {
   int TH, NI, mt;
 };
 
 static bool wino_tile(const lvae_conv_desc* d, WinoTile& w) {
-  const char* wsw = getenv("LVAE_WINO_WIDE");  // experiment switch, read per call (the parity tests run both forms in one process)
-  const bool wide_on = wsw != nullptr && atoi(wsw) != 0;
   int TH, NI;
-  if (wide_on && kpad_is64(d) && !wino_split_form(d) && wino_tile_for(d, 256, 384, TH, NI)) {
-    const int64_t groups = (int64_t)((d->N + NI - 1) / NI) * (d->H / TH) * ((d->Cout + 63) / 64);
-    if (groups >= 256) {
-      w = WinoTile{TH, NI, 2};
-      return true;
-    }
-  }
   if (!wino_tile_for(d, 128, 256, TH, NI)) return false;
   w = WinoTile{TH, NI, 1};
   return true;
+}
+
+// 0: this kernel would not run for d; LVAE_VARIANT_WINO_F32 / LVAE_VARIANT_WINO_SIX otherwise
+int conv3x3_wino_variant(const lvae_conv_desc* d) {
+  if (d->workspace == nullptr || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
+  WinoTile w;
+  if (!wino_tile(d, w)) return 0;
+  return wino_split_form(d) ? LVAE_VARIANT_WINO_SIX : LVAE_VARIANT_WINO_F32;
 }
 
 // rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
@@ -585,6 +610,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.m_wt_per_img = fastdiv_magic(a.wt_per_img);
   const int kpad = wino_kpad(d);
   a.Cin = Cin;
+  static const int dbg = lvae::debug_phase_switch("LVAE_WINO_DEBUG");
+  a.debug = dbg;
   size_t lds = (size_t)a.halo_px * (kpad + 4) * sizeof(float);
   const size_t lds_r = (size_t)4 * 2 * 32 * mt * WLDO * sizeof(float);
   if (lds < lds_r) lds = lds_r;
@@ -594,7 +621,6 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -612,8 +638,7 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (mt == 2) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 2, false>), grid, dim3(256), lds, s, a);
-  else if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
+  if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
   else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1, false>), grid, dim3(256), lds, s, a);
   else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, false>), grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2, 1, false>), grid, dim3(256), lds, s, a);

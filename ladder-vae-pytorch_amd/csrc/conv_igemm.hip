@@ -386,8 +386,22 @@ extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
   return conv3x3_wino_eligible(d) ? conv3x3_wino_workspace(d) : 0;
 }
 
+namespace lvae {
+int conv3x3_wino_variant(const lvae_conv_desc* d);
+}
+
+extern "C" int32_t lvae_conv2d_variant(const lvae_conv_desc* d) {
+  if (d == nullptr || tune("LVAE_DISABLE_HALO", 0) != 0) return LVAE_VARIANT_DIRECT;
+  if (conv3x3_pos_eligible(d)) return LVAE_VARIANT_POS;
+  const int form = conv3x3_bf16_form(d);
+  if (form != 0 && d->workspace != nullptr && (size_t)d->workspace_bytes >= conv3x3_bf16_workspace(d, form))
+    return form == 1 ? LVAE_VARIANT_BF16_DIRECT : LVAE_VARIANT_SIX_DIRECT;
+  const int w = conv3x3_wino_variant(d);
+  return w ? w : LVAE_VARIANT_DIRECT;
+}
+
 extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
-  if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
+  if (d == nullptr || tune("LVAE_DISABLE_HALO", 0) != 0) return 0;
   const int p = conv3x3_pos_stats_rows(d);
   if (p > 0) return p;
   const int form = conv3x3_bf16_form(d);
@@ -399,7 +413,7 @@ extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
 }
 
 extern "C" int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d) {
-  if (d == nullptr || getenv("LVAE_DISABLE_HALO") != nullptr) return 0;
+  if (d == nullptr || tune("LVAE_DISABLE_HALO", 0) != 0) return 0;
   return conv3x3_pos_eligible(d) ? 1 : 0;
 }
 
@@ -412,7 +426,7 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   LVAE_REQUIRE(d->stats_out == nullptr || d->stats_mode == LVAE_STATS_BN_FWD ||
                    (d->stats_mode == LVAE_STATS_BN_BWD && d->stats_x != nullptr && (reinterpret_cast<uintptr_t>(d->stats_x) & 15) == 0),
                LVAE_EINVAL, "lvae_conv2d_f32: bad stats_mode / stats_x");
-  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;  // A/B switch for profiling only
+  static const bool halo_off = tune("LVAE_DISABLE_HALO", 0) != 0;  // A/B switch (tuning builds only)
   LVAE_REQUIRE(d->in_fold == nullptr || (!halo_off && conv3x3_pos_eligible(d) && d->in_fold->parts != nullptr &&
                                           d->in_fold->rows > 0 && d->in_fold->M > 0 && d->in_scale == nullptr),
                LVAE_EINVAL, "lvae_conv2d_f32: in_fold set but lvae_conv2d_folds_bn_finalize(d) == 0 (or bad parts / rows / M, or in_scale given too)");

@@ -516,7 +516,7 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(dy && dw && workspace, LVAE_EINVAL, "lvae_conv2d_wgrad_f32: null dy/dw/workspace");
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
-  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  static const bool halo_off = tune("LVAE_DISABLE_HALO", 0) != 0;
   if (!halo_off && conv3x3_wgrad_bf16_workspace(d)) {
     const int hr = conv3x3_wgrad_bf16_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
@@ -603,7 +603,7 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
   LVAE_REQUIRE(descs && dy && dw && db && n > 0 && n <= 4096 && workspace, LVAE_EINVAL, "lvae_conv2d_wgrad_grouped_f32: bad arguments");
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_grouped_workspace(descs, n), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_grouped_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_grouped_workspace(descs, n));
-  static const bool halo_off = getenv("LVAE_DISABLE_HALO") != nullptr;
+  static const bool halo_off = tune("LVAE_DISABLE_HALO", 0) != 0;
   std::vector<void*> ws(n);
   std::vector<int> kind(n);
   char* wp = static_cast<char*>(workspace);
@@ -619,7 +619,7 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     const bool groupable = !halo_off && !wino && !bf16 && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
                            conv1x1_wgrad_workspace(&descs[i]) == 0;
     // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
-    static const int64_t wino_group_max = getenv("LVAE_WINO_GROUP_MAX_M") ? atoll(getenv("LVAE_WINO_GROUP_MAX_M")) : 65536;  // tuning switch
+    static const int64_t wino_group_max = tune("LVAE_WINO_GROUP_MAX_M", 65536);
     kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < wino_group_max ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
                    : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1);
   }

@@ -18,8 +18,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 void set_error(const char* fmt, ...);
 
 // Phase-skip switches of the profiling builds (they make a kernel skip stages, i.e. produce wrong results): compiled out of the
-// product library. The remaining LVAE_* environment variables (listed in include/lvae_hip.h) only choose between kernel variants
-// that all pass the parity tests; each is read once, on first use, into a function-local `static const` (thread-safe in C++11).
+// product library, which reads NO environment variable at all (see tune() below and lvae_conv_desc.form).
 inline int debug_phase_switch(const char* name) {
 #ifdef LVAE_PHASE_DEBUG
   const char* v = getenv(name);
@@ -27,6 +26,20 @@ inline int debug_phase_switch(const char* name) {
 #else
   (void)name;
   return 0;
+#endif
+}
+
+// Thresholds between kernel variants and A/B switches. In the product library they are COMPILE-TIME constants: which kernel runs depends
+// only on the descriptor (its `form` field included), never on hidden process state. A -DLVAE_TUNING_ENV build (profiling tools only:
+// `make EXTRA=-DLVAE_TUNING_ENV`) reads LVAE_<name> from the environment once, on first use, so that thresholds can be swept without
+// rebuilding.
+inline int64_t tune(const char* name, int64_t dflt) {
+#ifdef LVAE_TUNING_ENV
+  const char* v = getenv(name);
+  return v ? atoll(v) : dflt;
+#else
+  (void)name;
+  return dflt;
 #endif
 }
 

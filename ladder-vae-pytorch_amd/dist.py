@@ -49,13 +49,16 @@ def bucket_slices(n, bucket_elems):
 
 def make_buckets(segments, bucket_elems):
     """Merge consecutive gradient segments (arena.segments, in completion order) into buckets of at least `bucket_elems` elements.
-    Returns [(lo, hi, last_segment_index)]: bucket k is complete when backward has left segment `last_segment_index`."""
+    A segment is (lo, hi) or (segment id, lo, hi): the id is the index the model's segment markers report (LadderVAE.grad_segments();
+    a segment without trainable parameters has no entry, so ids may have gaps); plain pairs are numbered by position.
+    Returns [(lo, hi, last_segment_id)]: bucket k is complete when backward has left segment `last_segment_id`."""
     out, lo = [], None
-    for i, (a, b) in enumerate(segments):
+    for i, seg in enumerate(segments):
+        sid, a, b = seg if len(seg) == 3 else (i,) + tuple(seg)
         if lo is None:
             lo = a
         if b - lo >= bucket_elems or i + 1 == len(segments):
-            out.append((lo, b, i))
+            out.append((lo, b, sid))
             lo = None
     return out
 
@@ -83,11 +86,14 @@ class GradAllReduce:
         elems = max(1, int(bucket_mb * (1 << 20) / 4))
         n = flat_grads.numel()
         if segments:
-            assert segments[0][0] == 0 and segments[-1][1] == n and all(a[1] == b[0] for a, b in zip(segments, segments[1:]))
+            rng = [tuple(sg[-2:]) for sg in segments]
+            assert rng[0][0] == 0 and rng[-1][1] == n and all(a[1] == b[0] for a, b in zip(rng, rng[1:]))
             self.buckets = make_buckets(segments, elems)
         else:
             self.buckets = [(lo, hi, None) for lo, hi in bucket_slices(n, elems)]
         self.by_segment = {last: k for k, (_, _, last) in enumerate(self.buckets) if last is not None}
+        # a marker of a segment that owns no bucket end must still flush buckets that ended at an earlier id it skipped over
+        self._ends = sorted(self.by_segment)
         self.on_gpu = flat_grads.is_cuda
         # RCCL collectives are plain kernel launches on the stream and can be captured into a hipGraph; gloo cannot
         self.capturable = dist.is_initialized() and dist.get_backend(group) == 'nccl'
@@ -120,6 +126,9 @@ class GradAllReduce:
         else:
             cur = torch.cuda.current_stream(self.flat.device)
             self.stream.wait_stream(cur)           # fork: everything issued so far (this bucket's last gradient kernel included)
+            from . import ops
+            for st in (ops._side.get('stream') or ()):
+                self.stream.wait_stream(st)        # weight-gradient kernels issued on side streams (async_wgrad) write this bucket too
             with torch.cuda.stream(self.stream):
                 for b in range(self.next_bucket, k + 1):
                     self._reduce(b)
@@ -128,9 +137,11 @@ class GradAllReduce:
     def segment_done(self, seg):
         if not (self.active and self.overlap):
             return
-        k = self.by_segment.get(seg)
-        if k is not None:
-            self._launch_through(k)
+        # every bucket whose last segment id is <= seg is complete (ids are in completion order)
+        import bisect
+        i = bisect.bisect_right(self._ends, seg)
+        if i > 0:
+            self._launch_through(self.by_segment[self._ends[i - 1]])
 
     def finish(self):
         """After backward: exchange whatever has not been enqueued yet and make the launch stream wait for all of it."""

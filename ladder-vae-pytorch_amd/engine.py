@@ -52,6 +52,8 @@ class TrainStep:
         self.static_x = None
         self.static_out = None
         self._bns = None
+        self.fallback_reason = None
+        self._table_ref = None
         if allreduce is not None and allreduce.world > 1:
             optimizer._state()
             optimizer.gscale = allreduce.scale
@@ -105,22 +107,45 @@ class TrainStep:
                 if fused:
                     self.opt.step()
         except Exception as e:  # noqa: BLE001
-            if not (self.overlap and self.allreduce is not None and self.allreduce.active):
-                raise
-            # a collective that refuses to be captured: keep the exchange outside the graphs (fwd+bwd graph | eager all-reduce |
-            # Adamax graph) instead of failing the run
-            print('[lvae] capturing the gradient exchange failed (%s: %s); falling back to LVAE_DDP_MODE=split' %
-                  (type(e).__name__, str(e).splitlines()[0] if str(e) else ''), file=sys.stderr, flush=True)
+            if not (self.overlap and self.allreduce is not None and self.allreduce.active and self._is_capture_error(e)):
+                raise   # a kernel / launch / shape error keeps its traceback: only a collective that refuses capture is retried
+            # keep the exchange outside the graphs (fwd+bwd graph | eager all-reduce | Adamax graph), in this same process
+            self.fallback_reason = '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
+            print('[lvae] capturing the gradient exchange failed (%s); continuing with the exchange outside the step graph '
+                  '(LVAE_DDP_MODE=split)' % self.fallback_reason, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             self.overlap = False
             self.model.grad_tracker = None
             self.graph_a = self.graph_b = None
+            for bn in self.model.bn_modules():      # the aborted capture ran the Python forward once: un-count its BatchNorm forwards
+                bn._pending -= 1
             return self._capture(x)
         if not fused:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
                 self.opt.step()
         self._bns = self.model.bn_modules()
+        # the captured prepare_all launch baked in the device address (and entry count) of the transformed-weight table: keep exactly
+        # that table, and the scratch buffers its entries point to, alive and unmodified for as long as this graph can be replayed
+        self._table_ref = K.prepared.pin_current()
+
+    @staticmethod
+    def _is_capture_error(e):
+        """True for errors raised because an operation is not permitted / not supported while the stream is capturing (hipGraph
+        capture invalidated, RCCL refusing a captured collective), False for everything else."""
+        msg = str(e).lower()
+        return any(k in msg for k in ('captur', 'hipgraph', 'cudagraph', 'graph', 'nccl', 'rccl', 'operation not permitted when stream'))
+
+    def exchange_description(self):
+        """How the gradients are exchanged in this process (bench.py's config.grad_exchange)."""
+        ar = self.allreduce
+        if ar is None or not ar.active:
+            return 'none (single rank)'
+        if self.overlap:
+            where = 'inside the step graph' if self.use_graph else 'eager launches'
+            return '%d completion-ordered buckets on a side stream during backward, %s' % (len(ar.buckets), where)
+        why = ' (fallback: %s)' % self.fallback_reason if getattr(self, 'fallback_reason', None) else ''
+        return '%d buckets after backward, outside the step graph (split)%s' % (len(ar.buckets), why)
 
     def _traced_split_step(self):
         ts = [time.perf_counter()]

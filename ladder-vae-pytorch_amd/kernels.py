@@ -20,6 +20,29 @@ _ws_cache = {}
 precision = PREC_F32
 
 
+# Arithmetic-form request (lvae_conv_desc.form) of every descriptor built from here on: FORM_AUTO in the product; the parity tests
+# walk the other forms (`with kernels.use_form(_C.FORM_F32_MFMA): ...`).
+form = _C.FORM_AUTO
+
+
+class use_form:
+    def __init__(self, f):
+        self.f = f
+
+    def __enter__(self):
+        global form
+        self.prev, form = form, self.f
+
+    def __exit__(self, *exc):
+        global form
+        form = self.prev
+
+
+BF16_MODE_NOTE = ('forward, dgrad and weight gradient of the 3x3 convolutions of the 8x8..32x32 levels and the GateLayer2d 1x1 family on '
+                  'v_mfma_f32_32x32x16_bf16 with bf16 operands; fp32 accumulate / statistics / KL / likelihood; merge 1x1 and <=4x4 '
+                  'convolutions fp32')
+
+
 def set_precision(dtype):
     global precision
     precision = {'f32': PREC_F32, 'fp32': PREC_F32, 'float32': PREC_F32, 'bf16': PREC_BF16, 'bfloat16': PREC_BF16}[str(dtype).replace('torch.', '')]
@@ -81,6 +104,7 @@ def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, b
     d.N, d.H, d.W, d.OH, d.OW, d.Cout = N, H, W, OH, OW, Cout
     d.KH, d.KW, d.stride, d.pad, d.gather = g.KH, g.KW, g.stride, g.pad, gather
     d.precision = precision
+    d.form = form
     return d
 
 
@@ -163,6 +187,14 @@ class _PreparedWeights:
                 w = e['weight']()
                 e['stamp'] = self.stamp(w) if w is not None else None
         return len(self.entries)
+
+    def pin_current(self):
+        """Called by a TrainStep right after it captured a graph containing prepare_all(): returns a handle that keeps the table the
+        captured launch reads, and every scratch buffer its entries point to, alive. A later change of the entry set (another batch
+        size, another model, evict_dead) builds a NEW table; the pinned one stays valid for the replays of that graph."""
+        if self.table is None:
+            return None
+        return (self.table, [e for e in self.entries.values()])   # the caller (the graph's owner) holds it; nothing here does
 
     def weights_written(self):
         """Call after weights were modified through raw pointers (optimizer kernel, collective, graph replay)."""

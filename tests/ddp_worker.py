@@ -4,6 +4,7 @@
   rccl1   one rank over RCCL with LVAE_FORCE_DIST=1: the N > 1 code path — completion-ordered buckets exchanged on the side stream
           while backward runs, all inside the captured graph
   gloo2   rank RANK of 2 over gloo, both ranks on the one GPU of the test box, eager launches (gloo cannot be captured)
+  gloo2a  the same with every weight-gradient kernel on one of two side streams (async_wgrad): a bucket's exchange must wait for them
   emul2   one process playing both ranks of gloo2 one after the other: per-shard forward/backward with per-rank BatchNorm
           statistics and noise, gradients summed, Adamax with the 1/2 scale — what gloo2 must reproduce
 usage: python tests/ddp_worker.py MODE OUT.pt STEPS
@@ -69,14 +70,15 @@ def main():
         assert step.graph_a is not None and step.graph_b is None      # ONE graph: backward, exchange and Adamax together
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'launched': ar.launched})
         torch.distributed.destroy_process_group()
-    elif mode == 'gloo2':
+    elif mode in ('gloo2', 'gloo2a'):   # gloo2a: weight-gradient kernels on side streams (async_wgrad) under the overlapped exchange
         rank, world, _ = ldist.init_from_env('gloo')
         torch.cuda.set_device(0)
         m, opt = build(rank)
         arena = m.pack()
         ldist.broadcast_flat(arena.params)
         ar = ldist.GradAllReduce(arena.grads, segments=arena.segments, bucket_mb=0.25)
-        step = TrainStep(m, opt, use_graph=True, allreduce=ar)   # TrainStep itself must refuse to capture a gloo exchange
+        step = TrainStep(m, opt, use_graph=True, allreduce=ar, async_wgrad=(mode == 'gloo2a'), wgrad_streams=2,
+                         wgrad_group_rows=(0 if mode == 'gloo2a' else 16384) or None)   # TrainStep itself must refuse to capture a gloo exchange
         assert step.overlap and not step.use_graph
         lo, hi = ldist.shard_batch(PER_RANK * world, rank, world)
         orders = []

@@ -123,11 +123,14 @@ def test_forced_rccl_rank_overlapped_graph_step_matches_single_rank(tmp_path):
     assert nb >= 3 and rb['extra']['launched'] == list(range(nb))     # every bucket exchanged once, in completion order
 
 
-def test_two_gloo_ranks_on_one_gpu_match_two_rank_emulation(tmp_path):
+@pytest.mark.parametrize('mode', ['gloo2', 'gloo2a'])
+def test_two_gloo_ranks_on_one_gpu_match_two_rank_emulation(tmp_path, mode):
+    """gloo2a: weight-gradient kernels on side streams while buckets are exchanged during backward — a bucket's all-reduce
+    must be ordered behind the side-stream kernels that accumulate into it, or the ranks sum stale gradients."""
     e, g = str(tmp_path / 'emul.pt'), str(tmp_path / 'gloo.pt')
     _run('emul2', e, 2)
     port = _free_port()
-    procs = [_run('gloo2', g, 2, rank=r, world=2, port=port, wait=False) for r in range(2)]
+    procs = [_run(mode, g, 2, rank=r, world=2, port=port, wait=False) for r in range(2)]
     logs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]

@@ -111,8 +111,9 @@ def test_arena_is_laid_out_in_gradient_completion_order():
     ids = [m.grad_segment_of(k) for k in arena.names[:len([p for p in m.parameters() if p.requires_grad])]]
     assert ids == sorted(ids) and set(ids) == set(range(len(segs)))
     assert m.grad_segment_of('top_down_layers.2.top_prior_params') == len(segs) - 1      # arrives via autograd accumulation: last
-    assert len(arena.segments) == len(segs) and arena.segments[0][0] == 0 and arena.segments[-1][1] == arena.n_train
-    assert all(a[1] == b[0] for a, b in zip(arena.segments, arena.segments[1:]))
+    assert len(arena.segments) == len(segs) and arena.segments[0][1] == 0 and arena.segments[-1][2] == arena.n_train
+    assert [sg[0] for sg in arena.segments] == list(range(len(segs)))       # explicit ids: what the model's segment markers report
+    assert all(a[2] == b[1] for a, b in zip(arena.segments, arena.segments[1:]))
     # slots still address every parameter; values survived the permutation; state_dict order is the registration order
     assert list(k for k, _ in m.named_parameters()) == reg_order
     for k, p in m.named_parameters():
@@ -122,3 +123,40 @@ def test_arena_is_laid_out_in_gradient_completion_order():
     assert len(bk) == len(segs) and [b[2] for b in bk] == list(range(len(segs)))
     bk = make_buckets(arena.segments, arena.n_train)
     assert bk == [(0, arena.n_train, len(segs) - 1)]
+
+
+def test_segment_ids_with_gaps_keep_buckets_aligned():
+    """A segment without trainable parameters has no arena range; the markers still report model-level ids (positional
+    indices would shift every later bucket by one and launch it before its gradients exist)."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd.dist import GradAllReduce, make_buckets
+    segs = [(0, 0, 100), (2, 100, 300), (3, 300, 350), (5, 350, 1000)]      # ids 1 and 4 own nothing
+    assert make_buckets(segs, 1) == [(0, 100, 0), (100, 300, 2), (300, 350, 3), (350, 1000, 5)]
+    assert make_buckets(segs, 250) == [(0, 300, 2), (300, 1000, 5)]
+    g = torch.zeros(1000)
+    ar = GradAllReduce(g, bucket_mb=4 * 250 / (1 << 20), segments=segs)
+    assert ar.buckets == [(0, 300, 2), (300, 1000, 5)] and ar.by_segment == {2: 0, 5: 1}
+    # not active (world 1): segment_done is a no-op, but the id -> bucket search must still be exact
+    import bisect
+    ends = ar._ends
+    assert [bisect.bisect_right(ends, s) for s in range(6)] == [0, 0, 1, 1, 1, 2]
+
+
+def test_bench_self_launches_its_ranks_as_child_processes():
+    """`python bench.py --gpus N` without WORLD_SIZE starts the N ranks itself (torch.distributed.run as a CHILD
+    process, never an exec), relays rank 0's JSON line, and exits non-zero when a child does. Rehearsed over gloo without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'LVAE_FORCE_DIST')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--launch-check']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['value'] == 3.0 and rec['self_launched'] is True     # 1 + 2: both ranks took part
+    env['LVAE_LAUNCH_CHECK_FAIL_RANK'] = '1'
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0

@@ -105,25 +105,25 @@ WINO_CASES = [
     (64, 64, 16, 16),    # fewer than 256 pixel tiles: the 32-channel-per-workgroup variant with the pinned weight ring
     (257, 100, 8, 8),    # ... ragged last channel block, two images per tile, ragged last tile
     (300, 32, 8, 8),     # ... a single channel block
-    (257, 64, 16, 16),   # LVAE_WINO_WIDE=1, >= 256 pixel tiles of 256 pixels: one workgroup per CU, 512 registers per wave (MT = 2); ragged batch
-    (65, 64, 32, 32),    # ... 8-row tiles of a 32-wide image
-    (130, 100, 16, 16),  # ... two output-channel tiles, the second ragged
-    (300, 32, 24, 16),   # ... 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
+    (257, 64, 16, 16),   # ragged batch
+    (65, 64, 32, 32),    # 8-row tiles of a 32-wide image
+    (130, 100, 16, 16),  # two output-channel tiles, the second ragged
+    (300, 32, 24, 16),   # 192-pixel tile: 16 of the 64 Winograd tile slots stay unused
 ]
 
 
 @pytest.mark.parametrize('form', ['winograd', 'winograd6', 'split'])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_conv3x3_winograd(K, case, form, monkeypatch):
+def test_conv3x3_winograd(K, case, form):
     """Large 3x3 stride-1 layers in fp32 run as Winograd F(2x2,3x3) with the 16 position GEMMs either on the fp32 MFMA ('winograd',
-    LVAE_WINO_SPLIT=0) or as six exact bf16-piece products per fp32 product on the bf16 MFMA ('winograd6', the default), or as a direct
-    convolution in the six-product form ('split', LVAE_F32_SPLIT=1); all must agree with the direct sum to a few ulp of fp32, including
-    the fused BN/activation prologue and dropout/activation epilogue."""
-    monkeypatch.setenv('LVAE_F32_SPLIT', '1' if form == 'split' else '0')
-    monkeypatch.setenv('LVAE_WINO_SPLIT', '1' if form == 'winograd6' else '0')
-    monkeypatch.setenv('LVAE_F32_SPLIT_WGRAD', '1' if form == 'split' else '0')   # weight gradient: fp32 MFMA / six-product bf16 form
-    wide = form == 'winograd' and (case[0] in (257, 65, 130) or case == (300, 32, 24, 16))
-    monkeypatch.setenv('LVAE_WINO_WIDE', '1' if wide else '0')   # 256-pixel workgroups (MT = 2), fp32 MFMA form only
+    lvae_conv_desc.form = LVAE_FORM_F32_MFMA) or as six exact bf16-piece products per fp32 product on the bf16 MFMA ('winograd6', the
+    default), or as a direct convolution in the six-product form ('split', LVAE_FORM_SIX_PRODUCT_DIRECT); all must agree with the direct
+    sum to a few ulp of fp32, including the fused BN/activation prologue and dropout/activation epilogue."""
+    with K.use_form({'winograd': K._C.FORM_F32_MFMA, 'winograd6': K._C.FORM_AUTO, 'split': K._C.FORM_SIX_PRODUCT_DIRECT}[form]):
+        _conv3x3_winograd_case(K, case, form)
+
+
+def _conv3x3_winograd_case(K, case, form):
     N, Co, H, W = case
     C = 64
     g = torch.Generator().manual_seed(sum(case))
@@ -137,8 +137,22 @@ def test_conv3x3_winograd(K, case, form, monkeypatch):
     wp = packed_weight(w)
     geom = K.ConvGeom(wp, 1, 1)
     d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
+    need = K._C.load().lvae_conv2d_workspace(ctypes.byref(d))
     if form != 'split':
-        assert K._C.load().lvae_conv2d_workspace(ctypes.byref(d)) > 0, "case is meant to exercise the Winograd path"
+        assert need > 0, "case is meant to exercise the Winograd path"
+    if need:
+        scratch = torch.empty(need, dtype=torch.uint8, device='cuda')
+        d.workspace, d.workspace_bytes = scratch.data_ptr(), need
+        var = K._C.load().lvae_conv2d_variant(ctypes.byref(d))
+        V = K._C
+        if form == 'winograd':
+            assert var == V.VARIANT_WINO_F32
+        elif form == 'winograd6':   # the six-product form needs 64 reduction channels and at least 256 pixel tiles
+            assert var in (V.VARIANT_WINO_SIX, V.VARIANT_WINO_F32)
+            if case in ((200, 64, 16, 16), (257, 64, 16, 16), (65, 64, 32, 32)):
+                assert var == V.VARIANT_WINO_SIX
+        else:
+            assert var == V.VARIANT_SIX_DIRECT
     yd = K.conv2d(nhwc(x), wp, geom, bias=b.cuda(), in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu',
                   out_scale=drop.cuda(), out_act='elu')
     assert rel(nchw(yd), y) < 4e-6
@@ -301,8 +315,8 @@ def test_bn_stats_and_affine_bwd(K, shape):
                                    (37, 64, 3, 3)])     # ... ragged last tile
 def test_conv1x1_gate_fused(K, shape, form, monkeypatch):
     """GateLayer2d forward fused with its 1x1 convolution; both fp32 forms of the persistent kernel (six exact bf16-piece products per
-    fp32 product on the bf16 MFMA, LVAE_GATE_FWD_F32_SPLIT=1, and the fp32 MFMA, the default)."""
-    monkeypatch.setenv('LVAE_GATE_FWD_F32_SPLIT', '0' if form == 'mfma_f32' else '1')
+    fp32 product on the bf16 MFMA, lvae_conv_desc.form = LVAE_FORM_SIX_PRODUCT, and the fp32 MFMA, the default)."""
+    monkeypatch.setattr(K, 'form', K._C.FORM_F32_MFMA if form == 'mfma_f32' else K._C.FORM_SIX_PRODUCT)
     N, C, H, W = shape
     g = torch.Generator().manual_seed(11)
     x, res = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
@@ -726,8 +740,8 @@ def test_conv3x3_bf16_operands(K, case):
 def test_conv1x1_gate_bwd_with_fused_weight_gradient(K, shape, form, monkeypatch):
     """lvae_conv1x1_gate_bwd_wgrad_f32 (gate derivative + dgrad + weight / bias gradient of the gate convolution, one persistent
     kernel) == autograd of lib/nn.py:118-126, accumulating into non-zero gradient buffers. Both fp32 forms: six exact bf16-piece
-    products per fp32 product on the bf16 MFMA (default) and the fp32 MFMA (LVAE_GATE_BWD_F32_MFMA=1)."""
-    monkeypatch.setenv('LVAE_GATE_BWD_F32_MFMA', '1' if form == 'mfma_f32' else '0')
+    products per fp32 product on the bf16 MFMA (default) and the fp32 MFMA (lvae_conv_desc.form = LVAE_FORM_F32_MFMA)."""
+    monkeypatch.setattr(K, 'form', K._C.FORM_F32_MFMA if form == 'mfma_f32' else K._C.FORM_AUTO)
     N, H, W = shape
     C = 64
     g = torch.Generator().manual_seed(N + H)
