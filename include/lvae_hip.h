@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 12
+#define LVAE_ABI_VERSION 13
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -42,6 +42,12 @@ extern "C" {
 /* activation ids shared by every kernel (models/lvae.py:64-69 nonlin table) */
 enum { LVAE_STATS_BN_FWD = 0, LVAE_STATS_BN_BWD = 1 };
 enum { LVAE_PREC_F32 = 0, LVAE_PREC_BF16 = 1 };
+/* Storage type of an activation tensor (lvae_conv_desc.x_dtype / y_dtype / stats_x_dtype and the `dtypes` masks below). bf16 storage exists
+ * for the tensors INSIDE a residual block under precision = LVAE_PREC_BF16 (conv outputs y1 / y2, the gate pre-activations ab and their
+ * gradients): what torch.autocast(bfloat16) stores for the reference's nn.Conv2d outputs (BASELINE configs[1], [3], [4]). The residual
+ * stream, statistics, KL / likelihood terms, parameters and their gradients stay fp32. lvae_resblock_bf16_storage() says whether every kernel
+ * of a block's forward and backward has the bf16-storage form for a shape; kernels without it reject bf16 tensors (LVAE_EINVAL). */
+enum { LVAE_DT_F32 = 0, LVAE_DT_BF16 = 1 };
 /* lvae_conv_desc.form: which arithmetic form an fp32 (LVAE_PREC_F32) descriptor asks for. All forms pass the same parity tests. */
 enum {
   LVAE_FORM_AUTO = 0,               /* the library's choice for the shape (what the training step uses) */
@@ -108,8 +114,10 @@ typedef struct lvae_conv_desc {
   int32_t KH, KW, stride, pad;
   int32_t gather;        /* LVAE_GATHER_* */
   int32_t precision;     /* LVAE_PREC_F32 (0): results as an fp32 multiply-add chain (fp32 MFMA, Winograd, or six exact bf16-piece
-                            products per fp32 product: finite inputs only differ from the fp32 MFMA by terms below 2^-24 of a product;
-                            an infinite operand gives NaN there, where an fp32 multiply would give +-inf); LVAE_PREC_BF16: operands rounded to bf16 at the matrix-core input, fp32
+                            products per fp32 product: finite inputs — of any magnitude up to FLT_MAX, denormals included — only differ from the
+                            fp32 MFMA by terms below 2^-24 of a product; an infinite operand gives NaN there, where an fp32 multiply would give
+                            +-inf. Winograd (either form) spreads a non-finite input to every output of the tiles whose 4x4 block contains
+                            it and to no other; tests/test_forms_gpu.py pins all of this); LVAE_PREC_BF16: operands rounded to bf16 at the matrix-core input, fp32
                             accumulate (kernel variants that have no bf16 form run in fp32) */
   void* workspace;       /* scratch for lvae_conv2d_f32 (transformed weights of the Winograd path) or NULL */
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
@@ -128,6 +136,11 @@ typedef struct lvae_conv_desc {
   /* Folded BatchNorm finalize of the INPUT: NULL, or a HOST pointer to the block below (read by the launcher, not by the device) */
   const struct lvae_bn_fold* in_fold;
   int32_t form;           /* LVAE_FORM_* (0 = LVAE_FORM_AUTO) */
+  /* one byte each (they share the 8 bytes `form` occupies: grouped launches pass twelve descriptors in one 4 KB kernel-argument block) */
+  uint8_t x_dtype;        /* LVAE_DT_*: element type of x (and x2); the pointer fields keep their float* spelling */
+  uint8_t y_dtype;        /* LVAE_DT_*: element type of y (lvae_conv2d_wgrad_*: of dy) */
+  uint8_t stats_x_dtype;  /* LVAE_DT_*: element type of stats_x */
+  uint8_t reserved_;      /* 0 */
 } lvae_conv_desc;
 
 /* Scratch bytes lvae_conv2d_f32 can use for `d` (0 when no variant needs any). Large 3x3 / stride-1 / 64-channel layers run
@@ -146,6 +159,10 @@ enum {
   LVAE_VARIANT_SIX_DIRECT = 6    /* direct 3x3, six-product form (form LVAE_FORM_SIX_PRODUCT_DIRECT) */
 };
 int32_t lvae_conv2d_variant(const lvae_conv_desc* d);
+/* 1 when a residual block whose 3x3 convolutions look like `d` (a FORWARD descriptor: 64 -> 64 channels, precision LVAE_PREC_BF16, its
+ * workspace attached) can keep its internal tensors in bf16: forward, dgrad and weight gradient of the convolution, the GateLayer2d
+ * forward and its fused backward, and the BatchNorm-backward apply all have a bf16-storage form for N x H x W. 0 otherwise. */
+int32_t lvae_resblock_bf16_storage(const lvae_conv_desc* d);
 /* The same convolution with bf16 matrix-core operands (v_mfma_f32_32x32x16_bf16): activations (after the fused input transform)
  * and weights are rounded to bf16, products are exact, accumulation, bias, statistics and the stored result are fp32 — the
  * arithmetic of the reference's nn.Conv2d call sites under torch.autocast(bfloat16) (BASELINE configs[1], [3], [4]). Equivalent to
@@ -267,7 +284,8 @@ int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t M, int32_t 
 int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, const float* dh, const float* x, int64_t M, int32_t C,
                                   const float* scale, const float* shift, int32_t act, const float* mean, const float* rstd,
                                   float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n, const float* add,
-                                  float* dx, void* workspace, size_t workspace_bytes, void* stream);
+                                  float* dx, void* workspace, size_t workspace_bytes, int32_t dtypes, void* stream);
+/* dtypes: bit 0 dh, bit 1 x, bit 2 dx stored as bf16 (LVAE_DT_BF16), else fp32; `add` and everything else fp32. */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GateLayer2d epilogue + residual add — lib/nn.py:121-126 and lib/nn.py:99

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'liblvae_hip.so')
 ACT = {None: 0, 'none': 0, 'elu': 1, 'relu': 2, 'leakyrelu': 3, 'selu': 4}
 GATHER_CONV, GATHER_TRANSPOSED = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
+DT_F32, DT_BF16 = 0, 1
 VARIANT_DIRECT, VARIANT_POS, VARIANT_WINO_F32, VARIANT_WINO_SIX, VARIANT_BF16_DIRECT, VARIANT_SIX_DIRECT = 0, 2, 3, 4, 5, 6
 FORM_AUTO, FORM_F32_MFMA, FORM_SIX_PRODUCT, FORM_SIX_PRODUCT_DIRECT = 0, 1, 2, 3
 
@@ -34,7 +35,7 @@ class ConvDesc(C.Structure):
         ('gather', C.c_int32), ('precision', C.c_int32), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('workspace_ready', C.c_int32), ('stats_out', C.c_void_p), ('stats_pivot', C.c_void_p), ('stats_mode', C.c_int32), ('stats_act', C.c_int32),
         ('stats_x', C.c_void_p),
         ('in_fold', C.c_void_p),
-        ('form', C.c_int32),
+        ('form', C.c_int32), ('x_dtype', C.c_uint8), ('y_dtype', C.c_uint8), ('stats_x_dtype', C.c_uint8), ('reserved_', C.c_uint8),
     ]
 
 
@@ -45,7 +46,7 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 12  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 13  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -58,6 +59,7 @@ SIGNATURES = {
     'lvae_conv2d_bf16': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_variant': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_resblock_bf16_storage': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_folds_bn_finalize': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_prepare_entry_bytes': (_Z, []),
     'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
@@ -78,7 +80,7 @@ SIGNATURES = {
     'lvae_bn_eval_coeffs_f32': (C.c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'lvae_affine_act_f32': (C.c_int, [_P, _L, _I, _P, _P, _I, _P, _L, _P, _P]),
     'lvae_affine_act_bwd_f32': (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
-    'lvae_affine_act_bwd_parts_f32': (C.c_int, [_P, _I, _P, _P, _L, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
+    'lvae_affine_act_bwd_parts_f32': (C.c_int, [_P, _I, _P, _P, _L, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _Z, _I, _P]),
     'lvae_gate_fwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'lvae_gate_bwd_f32': (C.c_int, [_P, _P, _L, _I, _I, _P, _P]),
     'lvae_act_bwd_from_out_f32': (C.c_int, [_P, _P, _L, _I, _P, _P]),
@@ -145,7 +147,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise LvaeHipError("lvae_hip kernels need CUDA/HIP tensors; got a %s tensor (no CPU fallback exists)" % t.device)
-    if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.uint8:
+    if t.dtype not in (torch.float32, torch.bfloat16, torch.int64, torch.uint8):
         raise LvaeHipError("unexpected dtype %s" % t.dtype)
     return t.data_ptr()
 

@@ -42,6 +42,7 @@ struct GbfArgs {
   float* slab_w;       // [nwg][64 ci][128 co]
   float* slab_b;       // [nwg][128] or null
   int M, ohw, ntiles, act;
+  int in_bf16, dx_bf16;  // storage of ab and y (lvae_conv_desc.x_dtype) and of dx (y_dtype); dout is fp32. bf16-operand kernel only.
 };
 
 constexpr int GB_LDA = 132;  // dab / weight row pitch (floats): conflict-free ds_read_b128 (as conv1x1.hip)
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       const int m = m0 + r0 + 32 * u;
       const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
       pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
-      pa[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + c4);
-      pb[u] = *reinterpret_cast<const f32x4*>(a.ab + mc * 128 + 64 + c4);
-      py[u] = *reinterpret_cast<const f32x4*>(a.y + mc * 64 + c4);
+      pa[u] = load4_dt(a.ab, mc * 128 + c4, a.in_bf16 != 0);
+      pb[u] = load4_dt(a.ab, mc * 128 + 64 + c4, a.in_bf16 != 0);
+      py[u] = load4_dt(a.y, mc * 64 + c4, a.in_bf16 != 0);
     }
   };
 
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       if (m < a.M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
         if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
-        store_wt4(a.dx + (size_t)m * 64 + c4, v);
+        store4_dt(a.dx, (size_t)m * 64 + c4, v, a.dx_bf16 != 0);
       }
     }
     // no barrier here: the next write to the staging tile comes after the next iteration's first barrier
@@ -396,6 +397,9 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
   a.ohw = d->H * d->W;
   a.ntiles = (a.M + 63) / 64;
   a.act = act;
+  a.in_bf16 = d->x_dtype == LVAE_DT_BF16;
+  a.dx_bf16 = d->y_dtype == LVAE_DT_BF16;
+  if ((a.in_bf16 || a.dx_bf16) && d->precision != LVAE_PREC_BF16) return -1000;  // bf16 storage exists in the bf16-operand kernel only
   const int nwg = gbf_nwg(a.M);
   a.slab_w = static_cast<float*>(workspace);
   a.slab_b = db ? a.slab_w + (size_t)nwg * 64 * 128 : nullptr;

@@ -33,6 +33,7 @@ struct GateFwdArgs {
   float* stats_out;   // [gridDim.x + 1][2][64] or null (last row: the pivot)
   const float* stats_pivot;
   int M, tiles, act;
+  int x_bf16, y_bf16;  // storage of x and of ab (lvae_conv_desc.x_dtype / y_dtype); res and out are fp32
 };
 
 constexpr int GF_BM = 64, GF_LDA = 68;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
       const int m = tile * GF_BM + r;
-      av[u] = *reinterpret_cast<const f32x4*>(a.x + (size_t)(m < M ? m : 0) * 64 + k);
+      av[u] = load4_dt(a.x, (size_t)(m < M ? m : 0) * 64 + k, a.x_bf16 != 0);
     }
   };
   auto store_a = [&](float* dst) {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
               sv2 += dl * dl;
             }
           } else if (m < M) {
-            store_wt4(a.y + (size_t)m * 128 + pass * 64 + wn * 32 + c4, v);
+            store4_dt(a.y, (size_t)m * 128 + pass * 64 + wn * 32 + c4, v, a.y_bf16 != 0);
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
       const int m = m0 + (r & 3) + 8 * (r >> 2);
       if (m < M) {
         const float va = acc0[r] + bias_a, vb = acc1[r] + bias_b;
-        if (a.y) {
+        if (a.y) {  // (this store form is fp32 only: the launcher takes the WT form for bf16 storage)
           a.y[(size_t)m * 128 + ch] = va;
           a.y[(size_t)m * 128 + 64 + ch] = vb;
         }
@@ -313,13 +314,16 @@ int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, 
   a.M = (int)((int64_t)d->N * d->H * d->W);
   a.tiles = (a.M + GF_BM - 1) / GF_BM;
   a.act = act;
+  a.x_bf16 = d->x_dtype == LVAE_DT_BF16;
+  a.y_bf16 = d->y_dtype == LVAE_DT_BF16;
   static const bool wt = tune("LVAE_GATE_FWD_WT", 1) != 0;  // A/B switch (tuning builds only)
   const bool al = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d->y) |
                     reinterpret_cast<uintptr_t>(d->stats_pivot)) & 15) == 0;
   // fp32: on the fp32 MFMA by default (the kernel is HBM-bound: the six-product form measured the same); d->form = LVAE_FORM_SIX_PRODUCT asks for it
   const int split = d->precision == LVAE_PREC_BF16 ? 1 : (d->form == LVAE_FORM_SIX_PRODUCT ? 3 : 0);
   const dim3 grid(wgs), block(256);
-  if (wt && al) {
+  if ((a.x_bf16 || a.y_bf16) && !(split == 1 && al)) return -1000;  // bf16 storage: bf16-operand form, aligned buffers
+  if ((wt || a.x_bf16 || a.y_bf16) && al) {
     if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1>), grid, block, 0, s, a);
     else if (split == 3) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 3>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 0>), grid, block, 0, s, a);

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
       sc = *reinterpret_cast<const f32x4*>(d.in_scale + c4);
       sh = *reinterpret_cast<const f32x4*>(d.in_shift + c4);
     }
-    const float* xc = d.x + c4;
+    const float* xc = d.x;
+    const bool xbf = d.x_dtype == LVAE_DT_BF16;
     const int px0 = t >> 4;
     for (int base = 0; base < total; base += 256 * 8) {
       f32x4 v[8];
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
         const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
         const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
         const bool ok = (idx < total) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & c_ok;
-        const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin) : 0u;
-        v[u] = *reinterpret_cast<const f32x4*>(xc + off);
+        const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin + c4) : 0u;
+        v[u] = load4_dt(xc, off, xbf);
         okm |= ok ? (1u << u) : 0u;
       }
 #pragma unroll
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (d.bias) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
     const int p0 = t >> 4;
-    float* yp = d.y + ((size_t)(n0 * d.H + oh0) * d.W + p0) * d.Cout + col;
+    const size_t ybase = ((size_t)(n0 * d.H + oh0) * d.W + p0) * d.Cout + col;  // element offset of this thread's first output
+    const bool ybf = d.y_dtype == LVAE_DT_BF16, sxbf = d.stats_x_dtype == LVAE_DT_BF16;
     const float* op = Os + p0 * LDO + c4;
     const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
 #pragma unroll
@@ -229,10 +231,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
           v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
         }
         v = act_fwd4(v, d.out_act);
-        store_wt4(yp + (size_t)q * 16 * d.Cout, v);
+        store4_dt(d.y, ybase + (size_t)q * 16 * d.Cout, v, ybf);
         if (d.stats_mode == LVAE_STATS_BN_BWD) {
           if (d.stats_out) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
+            const f32x4 xv = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col, sxbf);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   const int per_img = a.halo_h * a.halo_w;
   f32x4 xr[XV], dr[DV];
   unsigned xok = 0, dok = 0;
+  const bool xbf = d.x_dtype == LVAE_DT_BF16, dybf = d.y_dtype == LVAE_DT_BF16;
   auto prefetch = [&](int tile) {
     const int ig = fastdiv(tile, a.m_tiles_h), th_idx = tile - ig * a.tiles_h;
     const int n0 = ig * a.NI, oh0 = th_idx * a.TH;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
       const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
       const bool ok = (px < a.halo_px) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & cx_ok;
       const size_t off = ok ? ((size_t)(n * d.H + ih) * d.W + iw) * Cin + c4 : 0;
-      xr[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      xr[u] = load4_dt(d.x, off, xbf);
       xok |= ok ? (1u << u) : 0u;
     }
     dok = 0;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
       const int img = fastdiv(p, a.m_thw);
       const bool ok = (p < tile_px) & (n0 + img < d.N) & cd_ok;
       const size_t off = ok ? ((size_t)(n0 * d.H + oh0) * d.W + p) * d.Cout + co0 + c4 : 0;
-      dr[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
+      dr[u] = load4_dt(a.dy, off, dybf);
       dok |= ok ? (1u << u) : 0u;
     }
   };

@@ -32,7 +32,6 @@ struct WinoArgs {
   const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3; six-product form: bf16 [16][4 k16][Npad/32][3 pieces][64 lanes][8]
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, Cin;
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
-  int debug;  // phase-skip bits, -DLVAE_PHASE_DEBUG builds only (tools/wino_phase.sh); always 0 in the product
 };
 
 // Six-product form (conv3x3_wino_kernel<.., SPL = true>): U[p][k][n] split exactly into three bf16 pieces, stored in the B-fragment order of
@@ -149,6 +148,19 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
 
 constexpr int WLDO = 68;  // R row stride (floats)
 
+// In-kernel phase stamps of the profiling builds (-DLVAE_WINO_DBG with bit 64; tools/wino_phase.sh): s_memtime per wave at the phase
+// boundaries, written to a buffer of their own that nothing else reads. Never compiled into the product.
+#if defined(LVAE_WINO_DBG) && (LVAE_WINO_DBG & 64)
+__device__ unsigned long long g_wino_stamps[8192 * 8];
+#define WINO_STAMP(i)                                                                                           \
+  do {                                                                                                          \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                           \
+      g_wino_stamps[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define WINO_STAMP(i) do {} while (0)
+#endif
+
 // CIN: reduction channels padded to 64 or 128 (the DMoL head's dgrad reduces over 100).
 // NH: 32-wide output-channel blocks per workgroup. 2 = the layout described above. 1 (64 channels split over two workgroups) is
 // for layers with fewer than 256 pixel tiles (the 8x8 level at batch 256): it fills all CUs, halves the dependent MFMA chain
@@ -185,11 +197,12 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
-#ifdef LVAE_PHASE_DEBUG
-  const int dbg = a.debug;  // 1: no halo loads, 2: no transform/split/MFMA, 4: no output stores, 8: U from one hot KB, 16: no epilogue at all, 32: no split (MFMAs on raw bits)
+#ifdef LVAE_WINO_DBG  // compile-time phase-skip mask of the profiling builds (tools/wino_phase.sh); never defined in the product
+  constexpr int dbg = LVAE_WINO_DBG;  // 1: no halo loads, 2: no transform/split/MFMA, 4: no output stores, 8: U from one hot KB, 16: no epilogue at all, 32: no split (MFMAs on raw bits)
 #else
   constexpr int dbg = 0;
 #endif
+  WINO_STAMP(0);
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
   store_slice(0);
   load_slice(1);
   __syncthreads();
+  WINO_STAMP(1);
   if (!SPL) {
     // ---- U fragments of this wave: positions 4*wave + j, channel halves h; one float4 per (j, h, k-step), straight from L2
     const size_t slab = (size_t)a.Npad * CIN;
@@ -408,9 +422,16 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
       }
     }
   }
+  WINO_STAMP(2);
   __syncthreads();  // every wave is done with the halo patch: LDS becomes R[wave][b][tile][co]
+  WINO_STAMP(3);
   if (dbg & 16) {
-    if (acc[0][0][0][0] + acc[0][1][0][1] + acc[0][2][NH - 1][2] + acc[0][3][NH - 1][3] == 12345.678f) d.y[t] = 1.f;
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) keep += acc[0][j][h][j + h];
+    if (keep == 12345.678f) d.y[t] = 1.f;
     return;
   }
 
@@ -430,6 +451,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
         o[NT * WLDO] = r1;
       }
   __syncthreads();
+  WINO_STAMP(4);
   {
     const int c4 = (t % C4N) * 4, col = co0 + c4;
     f32x4 st1 = zero4, st2 = zero4, piv = zero4;  // BatchNorm partials of the stored values (d.stats_out)
@@ -481,6 +503,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
         }
       }
     }
+    WINO_STAMP(5);
     if (d.stats_out) {  // PG pixel groups x CW channels -> one row of partials per pixel tile (fixed order)
       __syncthreads();  // R is dead
       float* red = smem;
@@ -494,6 +517,331 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
         for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
         if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
       }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// conv3x3_wino2_kernel (round 3): the six-product form on 256 output pixels (64 Winograd tiles = two 32-tile blocks) x 64 output
+// channels per workgroup, 8 waves, ONE workgroup per CU.
+//
+// Why: in-kernel stamps of conv3x3_wino_kernel<64, 2, 1, true> at 256x16x16 (tools/wino_stamps.py; per wave: prologue 4.1 k cycles,
+// GEMM loop 25.7 k, inverse transform + stores 8.8 k) and its phase-skip builds (U pieces from one hot KB: 25.3 -> 20.8 us) say the loop
+// is bound by the stream of pre-split U pieces: 393 KB per workgroup, two workgroups per CU = 786 KB per CU through the L2 -> L1 -> VGPR
+// path, which delivers about 70 GB/s per CU (MI355X_MICROARCH.md, "Indexed rows"): 11 us of the 12 us the loop takes. The MFMAs (12.3 k
+// cycles per SIMD) and the vector work fit beside it. The stream shrinks only if a fetched fragment feeds more MFMAs, so here a wave
+// owns TWO positions (one of the two column pairs of a position row) for BOTH tile blocks: every 1 KB U fragment it loads is the B operand of
+// two MFMAs instead of one, the workgroup's 393 KB serve 256 pixels, and the per-CU stream halves. The register budget is unchanged
+// (2 blocks x 2 positions x 2 channel halves x 16 accumulators), an (s, position) iteration is 24 MFMAs = 768 cycles, so a ring of
+// two fragment sets (one iteration ahead) covers an L2 round trip; three sets spill (29.8 vs 23.6 us).
+//   * input transform: the wave needs three of the four pixel columns of its two block rows (t = d[ra] +- d[rb] for columns
+//     (0, 2, 1) or (2, 1, 3)): v_first = L0 - L1, v_second = L1 +- L2; 12 ds_read_b128 + 40 VALU per block and 16-channel step.
+//   * inverse transform: R[i][b] = sum_j M[i][j] A[j][b] needs both column pairs of row i, i.e. two waves: each writes its partial sums
+//     (pair 0: M0 + M1, M1; pair 1: M2, -M2 - M3) and the store pass adds them while it forms Y = A^T R. The eight partial arrays of one
+//     32-tile block are 139 KB of LDS, so the two blocks go through the exchange one after the other (the first block's stores drain
+//     while the second block is exchanged).
+// Eligibility (wino2_tile): six-product form, exactly 64 tiles per workgroup whose blocks are the first and second 128 pixels of the
+// workgroup's pixel tile, and at least 256 such workgroups; everything else keeps conv3x3_wino_kernel.
+// ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef LVAE_W2_SGB
+#define LVAE_W2_SGB 0
+#endif
+constexpr int W2_LDS_R = 8 * 2 * 32 * WLDO * 4;  // bytes of the partial-sum exchange of one block
+
+__global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
+  constexpr int CIN = 64, WLDA = CIN + 4, NSLICE = CIN / 16, CW = 64, C4N = CW / 4, PG = 512 / C4N, NH = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;  // [halo_px][WLDA]; reused as the partial sums [wave 8][b 2][32 tiles][WLDO] by the epilogue
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int prow = wave >> 1, jp = wave & 1;  // position row i, column pair: positions 4 i + 2 jp + {0, 1}
+  WINO_STAMP(0);
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % a.ntn;
+  const int tm = bid / a.ntn;
+  const int th_idx = tm % a.tiles_h, ig = tm / a.tiles_h;
+  const int n0 = ig * a.NI, oh0 = th_idx * a.TH, co0 = tile_n * CW;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- halo patch in four 16-channel slices; slot = (pixel, float4 within the slice); 128 pixels per pass of the 512 threads
+  constexpr int SLOTS = 3;  // halo_px <= 384 (checked by the launcher)
+  const int per_img = a.halo_h * a.halo_w;
+  const int hc4 = (t & 3) * 4;
+  unsigned hoff[SLOTS];
+  int hlds[SLOTS];
+#pragma unroll
+  for (int u = 0; u < SLOTS; ++u) {
+    const int px = (t >> 2) + 128 * u;
+    const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+    const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+    const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+    const bool ok = (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & (px < a.halo_px);
+    hoff[u] = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * a.Cin + hc4) : ~0u;
+    // slots beyond the patch write to a dump row of their own behind it (the LDS allocation is sized by the epilogue's exchange, far larger)
+    hlds[u] = px < a.halo_px ? px * WLDA + hc4 : a.halo_px * WLDA + 4 * t;
+  }
+  const bool bn_in = d.in_scale != nullptr;
+  f32x4 hreg[SLOTS];
+  unsigned hlive = 0;
+  auto load_slice = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      const bool live = hoff[u] != ~0u && 16 * c + hc4 < a.Cin;
+      const unsigned off = live ? hoff[u] + 16 * c : 0u;
+      hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      hlive = live ? hlive | (1u << u) : hlive & ~(1u << u);
+    }
+  };
+  auto store_slice = [&](int c) {  // straight-line: one wave-uniform branch (fused input transform or not), selects instead of lane branches
+    if (bn_in) {
+      const int cc = 16 * c + hc4 < a.Cin ? 16 * c + hc4 : 0;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(d.in_scale + cc);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(d.in_shift + cc);
+#pragma unroll
+      for (int u = 0; u < SLOTS; ++u) {
+        f32x4 w = act_fwd4(hreg[u] * sc + sh, d.in_act);
+        const bool live = (hlive >> u) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = live ? w[e] : 0.f;
+        *reinterpret_cast<f32x4*>(As + hlds[u] + 16 * c) = w;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SLOTS; ++u) {
+        f32x4 w = hreg[u];
+        const bool live = (hlive >> u) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = live ? w[e] : 0.f;
+        *reinterpret_cast<f32x4*>(As + hlds[u] + 16 * c) = w;
+      }
+    }
+  };
+  load_slice(0);
+
+  // ---- this lane's two Winograd tiles (one per block) -> the two pixel rows of the 4x4 block this wave's position row combines,
+  // and its three pixel columns in the order (L0, L1, L2) = (0, 2, 1) | (2, 1, 3): first position L0 - L1, second L1 + s2 * L2
+  const int ra = prow == 0 ? 0 : (prow == 2 ? 2 : 1);
+  const int rb = prow == 0 ? 2 : (prow == 1 ? 2 : (prow == 2 ? 1 : 3));
+  const float sgn = prow == 1 ? 1.f : -1.f;
+  const float s2 = jp ? -1.f : 1.f;
+  const int col0 = jp ? 2 : 0, col1 = jp ? 1 : 2, col2 = jp ? 3 : 1;
+  const float* pa[2];
+  const float* pb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int wt = li + 32 * m;  // n_wt == 64 (launcher)
+    const int wimg = fastdiv(wt, a.m_wt_per_img), wr = wt - wimg * a.wt_per_img;
+    const int wty = fastdiv(wr, a.m_tiles_x), wtx = wr - wty * a.tiles_x;
+    const int pbase = (wimg * a.halo_h + 2 * wty) * a.halo_w + 2 * wtx;
+    pa[m] = As + (size_t)(pbase + ra * a.halo_w) * WLDA + 8 * lh;
+    pb[m] = As + (size_t)(pbase + rb * a.halo_w) * WLDA + 8 * lh;
+  }
+
+  f32x16 acc[2][2][NH];  // [block][position of the pair][channel half]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][j][h][r] = 0.f;
+
+  store_slice(0);
+  load_slice(1);
+  __syncthreads();
+  WINO_STAMP(1);
+  {
+    // U pieces of (position p, k16 step s, channel block h, piece q): 1 KB wave loads, fetched two (s, position) iterations ahead
+    const int NB = a.Npad >> 5;
+    const __bf16* u3 = reinterpret_cast<const __bf16*>(a.U) + ((size_t)(co0 >> 5) * 3 * 64 + lane) * 8;
+#ifndef LVAE_W2_RING
+#define LVAE_W2_RING 2
+#endif
+    constexpr int BR = LVAE_W2_RING, NIT = 2 * NSLICE;
+    bf16x8 bq[BR][NH][3];
+    auto load_b = [&](int it, int buf) {  // it = 2 s + jj
+      const __bf16* p = u3 + (size_t)((4 * prow + 2 * jp + (it & 1)) * 4 + (it >> 1)) * NB * 1536;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[buf][h][q] = *reinterpret_cast<const bf16x8*>(p + (h * 3 + q) * 512);
+    };
+#pragma unroll
+    for (int it = 0; it < BR - 1; ++it) load_b(it, it);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // piece products in ascending order of magnitude
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    // Software pipeline: the A fragments (transform + exact three-piece split, ~60 vector instructions) of step k + 1 are computed
+    // while the 12 MFMAs of step k occupy the matrix unit; the last step of a 16-channel slice overlaps the staging of the next
+    // slice instead. Steps of a slice: (position jj, block m) = (0,0) (0,1) (1,0) (1,1).
+    auto make_af = [&](const f32x4 (&tl)[2][3], const f32x4 (&th)[2][3], int jj, int m, bf16x8 (&af)[3]) {
+      f32x4 vl, vh;
+      if (jj == 0) {
+        vl = tl[m][0] - tl[m][1];
+        vh = th[m][0] - th[m][1];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vl[e] = __builtin_fmaf(s2, tl[m][2][e], tl[m][1][e]);  // s2 = +-1: exact
+          vh[e] = __builtin_fmaf(s2, th[m][2][e], th[m][1][e]);
+        }
+      }
+      bf16x4 pl[3], ph[3];
+      split4<3>(vl, pl);
+      split4<3>(vh, ph);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) af[q] = bf16x8{pl[q][0], pl[q][1], pl[q][2], pl[q][3], ph[q][0], ph[q][1], ph[q][2], ph[q][3]};
+    };
+#pragma unroll
+    for (int s16 = 0; s16 < NSLICE; ++s16) {
+      f32x4 tl[2][3], th[2][3];  // t = d[ra] + sgn * d[rb] for the columns (L0, L1, L2), channels 16 s + 8 lh + {0..3 | 4..7}
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int c = cc == 0 ? col0 : (cc == 1 ? col1 : col2);
+          const f32x4 dal = *reinterpret_cast<const f32x4*>(pa[m] + c * WLDA + s16 * 16);
+          const f32x4 dah = *reinterpret_cast<const f32x4*>(pa[m] + c * WLDA + s16 * 16 + 4);
+          const f32x4 dbl = *reinterpret_cast<const f32x4*>(pb[m] + c * WLDA + s16 * 16);
+          const f32x4 dbh = *reinterpret_cast<const f32x4*>(pb[m] + c * WLDA + s16 * 16 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            tl[m][cc][e] = __builtin_fmaf(sgn, dbl[e], dal[e]);  // sgn = +-1: exact
+            th[m][cc][e] = __builtin_fmaf(sgn, dbh[e], dah[e]);
+          }
+        }
+      bf16x8 afc[3], afn[3];
+      make_af(tl, th, 0, 0, afc);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int jj = st >> 1, m = st & 1, it = 2 * s16 + jj;
+        if (m == 0 && it + BR - 1 < NIT) load_b(it + BR - 1, (it + BR - 1) % BR);
+        if (st < 3) {
+          make_af(tl, th, (st + 1) >> 1, (st + 1) & 1, afn);
+        } else if (s16 < NSLICE - 1) {
+          store_slice(s16 + 1);
+          if (s16 + 2 < NSLICE) load_slice(s16 + 2);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk)
+            acc[m][jj][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[PA[kk]], bq[it % BR][h][PB[kk]], acc[m][jj][h], 0, 0, 0);
+#if LVAE_W2_SGB
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, LVAE_W2_SGB, 0);  // vector instructions of the next step's fragments beside it
+        }
+#endif
+        if (st < 3) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) afc[q] = afn[q];
+        }
+      }
+      if (s16 < NSLICE - 1) __syncthreads();  // the next 16-channel slice is published
+    }
+  }
+  WINO_STAMP(2);
+  __syncthreads();  // every wave is done with the halo patch: LDS becomes the partial sums of one block
+  WINO_STAMP(3);
+
+  // ---- epilogue, one 32-tile block at a time. Partial sums of R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]:
+  // pair 0 holds (M0, M1) -> (M0 + M1, M1); pair 1 holds (M2, M3) -> (M2, -M2 - M3). Accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh.
+  float* Rs = smem;  // [wave][b][32 tiles][WLDO]
+  const int c4 = (t % C4N) * 4, col = co0 + c4;
+  f32x4 st1 = zero4, st2 = zero4, piv = zero4;  // BatchNorm partials of the stored values (d.stats_out)
+  if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
+  f32x4 bsh = piv, bmu = piv, brs = piv;  // LVAE_STATS_BN_BWD: piv = scale, then shift, mean, rstd of the [4][Cout] block
+  if (d.stats_out && d.stats_mode == LVAE_STATS_BN_BWD && col < d.Cout) {
+    bsh = *reinterpret_cast<const f32x4*>(d.stats_pivot + d.Cout + col);
+    bmu = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col);
+    brs = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col);
+  }
+  f32x4 bias = zero4;
+  if (d.bias && col < d.Cout) bias = *reinterpret_cast<const f32x4*>(d.bias + col);
+  const int thw = a.TH * a.TW;
+  const int nvalid = min(a.NI, d.N - n0) * thw;
+  float* yb = d.y + ((size_t)(n0 * d.H + oh0) * d.W) * d.Cout + col;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (m) {
+      WINO_STAMP(5);
+      __syncthreads();  // the store pass of block 0 has read its partial sums
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float m0 = acc[m][0][h][r], m1 = acc[m][1][h][r];
+        const float r0 = jp ? m0 : m0 + m1;
+        const float r1 = jp ? -m0 - m1 : m1;
+        float* o = Rs + (size_t)((wave * 2) * 32 + tile) * WLDO + h * 32 + li;
+        o[0] = r0;
+        o[32 * WLDO] = r1;
+      }
+    __syncthreads();
+    if (m == 0) WINO_STAMP(4); else WINO_STAMP(6);
+    if (col < d.Cout) {
+#pragma unroll
+      for (int q = 0; q < 128 / PG; ++q) {
+        const int p = 128 * m + t / C4N + PG * q;
+        if (p < nvalid) {
+          const int img = fastdiv(p, a.m_thw), pr = p - img * thw;
+          const int oy = fastdiv(pr, a.m_tw), ox = pr - oy * a.TW;
+          const int tile = (img * a.wt_per_img + (oy >> 1) * a.tiles_x + (ox >> 1)) & 31;
+          // R[i][b = ox&1][tile] = partial of wave 2 i + partial of wave 2 i + 1; Y[a = oy&1] = R0 + R1 + R2 | R1 - R2 - R3
+          const float* rp = Rs + (size_t)((ox & 1) * 32 + tile) * WLDO + c4;
+          constexpr int WS = 2 * 32 * WLDO;  // floats per wave
+          const int i0 = (oy & 1) ? 1 : 0;
+          f32x4 Rr[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            Rr[k] = *reinterpret_cast<const f32x4*>(rp + (2 * (i0 + k)) * WS) + *reinterpret_cast<const f32x4*>(rp + (2 * (i0 + k) + 1) * WS);
+          f32x4 v = (oy & 1) ? (Rr[0] - Rr[1] - Rr[2]) : (Rr[0] + Rr[1] + Rr[2]);
+          v = v + bias;
+          if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
+          v = act_fwd4(v, d.out_act);
+          store_wt4(yb + (size_t)p * d.Cout, v);
+          if (d.stats_mode == LVAE_STATS_BN_BWD) {
+            if (d.stats_out) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+                st1[j] += gj;
+                st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
+              }
+            }
+          } else {
+            const f32x4 dl = v - piv;
+            st1 += dl;
+            st2 += dl * dl;
+          }
+        }
+      }
+    }
+  }
+  WINO_STAMP(7);
+  if (d.stats_out) {  // PG pixel groups x CW channels -> one row of partials per workgroup (fixed order)
+    __syncthreads();  // the partial sums are dead
+    float* red = smem;
+    *reinterpret_cast<f32x4*>(red + (t / C4N) * CW + c4) = st1;
+    *reinterpret_cast<f32x4*>(red + PG * CW + (t / C4N) * CW + c4) = st2;
+    __syncthreads();
+    if (t < 2 * CW) {
+      const int c = t % CW, which = t / CW;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
+      if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
     }
   }
 }
@@ -554,8 +902,24 @@ struct WinoTile {
   int TH, NI, mt;
 };
 
+// conv3x3_wino2_kernel (256 pixels, 8 waves, six-product form): exactly 64 Winograd tiles per workgroup whose two 32-tile blocks are the
+// first and the second 128 pixels of the pixel tile (image widths 8, 16, 32, 64), and at least 256 such workgroups
+static bool wino2_tile(const lvae_conv_desc* d, int& TH, int& NI) {
+  static const bool off = tune("LVAE_DISABLE_WINO2", 0) != 0;  // A/B switch (tuning builds only)
+  if (off || !wino_split_form(d) || !wino_tile_for(d, 256, 384, TH, NI)) return false;
+  const int tiles_x = d->W / 2, wt_per_img = (TH / 2) * tiles_x;
+  if (NI * wt_per_img != 64 || 32 % tiles_x != 0) return false;
+  if (wt_per_img % 32 != 0 && 32 % wt_per_img != 0) return false;
+  const int64_t groups = (int64_t)((d->N + NI - 1) / NI) * (d->H / TH) * ((d->Cout + 63) / 64);
+  return groups >= 256;
+}
+
 static bool wino_tile(const lvae_conv_desc* d, WinoTile& w) {
   int TH, NI;
+  if (wino2_tile(d, TH, NI)) {
+    w = WinoTile{TH, NI, 2};
+    return true;
+  }
   if (!wino_tile_for(d, 128, 256, TH, NI)) return false;
   w = WinoTile{TH, NI, 1};
   return true;
@@ -610,10 +974,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.m_wt_per_img = fastdiv_magic(a.wt_per_img);
   const int kpad = wino_kpad(d);
   a.Cin = Cin;
-  static const int dbg = lvae::debug_phase_switch("LVAE_WINO_DEBUG");
-  a.debug = dbg;
   size_t lds = (size_t)a.halo_px * (kpad + 4) * sizeof(float);
-  const size_t lds_r = (size_t)4 * 2 * 32 * mt * WLDO * sizeof(float);
+  const size_t lds_r = mt == 2 ? (size_t)W2_LDS_R : (size_t)4 * 2 * 32 * WLDO * sizeof(float);
   if (lds < lds_r) lds = lds_r;
   if (lds > 160 * 1024) return -1000;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
@@ -622,6 +984,7 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -638,7 +1001,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
+  if (mt == 2) hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(512), lds, s, a);
+  else if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
   else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1, false>), grid, dim3(256), lds, s, a);
   else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, false>), grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv3x3_wino_kernel<128, 2, 1, false>), grid, dim3(256), lds, s, a);
@@ -698,3 +1062,9 @@ extern "C" int lvae_conv2d_prepare_weights(const void* entries, int32_t n, int32
   LVAE_LAUNCH_CHECK("wino_weight_batched");
   return conv3x3_bf16_prepare_batched(entries, n, npad, (hipStream_t)stream);  // entries of the bf16-pipe kernels (kind != 0)
 }
+
+#if defined(LVAE_WINO_DBG) && (LVAE_WINO_DBG & 64)
+extern "C" int lvae_debug_wino_stamps(void* host_out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lvae::g_wino_stamps), bytes < sizeof(lvae::g_wino_stamps) ? bytes : sizeof(lvae::g_wino_stamps));
+}
+#endif

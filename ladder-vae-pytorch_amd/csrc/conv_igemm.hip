@@ -400,6 +400,26 @@ extern "C" int32_t lvae_conv2d_variant(const lvae_conv_desc* d) {
   return w ? w : LVAE_VARIANT_DIRECT;
 }
 
+namespace lvae {
+size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d);
+size_t conv1x1_gate_bwd_fused_workspace(const lvae_conv_desc* d);
+}
+
+extern "C" int32_t lvae_resblock_bf16_storage(const lvae_conv_desc* d) {
+  if (d == nullptr || d->precision != LVAE_PREC_BF16 || d->C1 != 64 || d->C2 != 0 || d->Cout != 64 || d->gather != LVAE_GATHER_CONV) return 0;
+  if (lvae_conv2d_variant(d) != LVAE_VARIANT_BF16_DIRECT) return 0;
+  lvae_conv_desc t = *d;  // dgrad view of the same layer (same shape; only the gather differs for the kernel choice)
+  t.gather = LVAE_GATHER_TRANSPOSED;
+  if (lvae_conv2d_variant(&t) != LVAE_VARIANT_BF16_DIRECT) return 0;
+  if (conv3x3_wgrad_bf16_workspace(d) == 0) return 0;
+  lvae_conv_desc g = *d;  // the block's GateLayer2d: 1x1, 64 -> 128 forward; its fused backward is described by the 128 -> 64 dgrad view
+  g.KH = g.KW = 1; g.pad = 0; g.Cout = 128; g.in_scale = g.in_shift = nullptr; g.out_scale = nullptr; g.in_act = g.out_act = 0; g.in_fold = nullptr;
+  if (conv1x1_gate_fwd_wgs(&g) == 0) return 0;
+  g.C1 = 128; g.Cout = 64; g.w_sk = 1; g.w_sn = 128;
+  if (conv1x1_gate_bwd_fused_workspace(&g) == 0) return 0;
+  return 1;
+}
+
 extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
   if (d == nullptr || tune("LVAE_DISABLE_HALO", 0) != 0) return 0;
   const int p = conv3x3_pos_stats_rows(d);
@@ -427,6 +447,10 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
                    (d->stats_mode == LVAE_STATS_BN_BWD && d->stats_x != nullptr && (reinterpret_cast<uintptr_t>(d->stats_x) & 15) == 0),
                LVAE_EINVAL, "lvae_conv2d_f32: bad stats_mode / stats_x");
   static const bool halo_off = tune("LVAE_DISABLE_HALO", 0) != 0;  // A/B switch (tuning builds only)
+  LVAE_REQUIRE((d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32 && d->stats_x_dtype == LVAE_DT_F32) ||
+                   lvae_conv2d_variant(d) == LVAE_VARIANT_BF16_DIRECT,
+               LVAE_EINVAL, "lvae_conv2d_f32: bf16-stored tensors need the bf16 3x3 kernel (precision LVAE_PREC_BF16, lvae_conv2d_variant(d) == "
+                            "LVAE_VARIANT_BF16_DIRECT)");
   LVAE_REQUIRE(d->in_fold == nullptr || (!halo_off && conv3x3_pos_eligible(d) && d->in_fold->parts != nullptr &&
                                           d->in_fold->rows > 0 && d->in_fold->M > 0 && d->in_scale == nullptr),
                LVAE_EINVAL, "lvae_conv2d_f32: in_fold set but lvae_conv2d_folds_bn_finalize(d) == 0 (or bad parts / rows / M, or in_scale given too)");
@@ -498,6 +522,8 @@ extern "C" int lvae_conv1x1_gate_f32(const lvae_conv_desc* d, const float* res, 
                                            (reinterpret_cast<uintptr_t>(d->stats_pivot) & 15) == 0),
                LVAE_EINVAL, "lvae_conv1x1_gate_f32: stats_out set but lvae_conv1x1_gate_stats_rows(d) == 0");
   rc = conv1x1_gate_fwd_try(d, res, out, act, (hipStream_t)stream);
+  LVAE_REQUIRE(rc != -1000 || (d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32), LVAE_EINVAL,
+               "lvae_conv1x1_gate_f32: bf16-stored x / ab need the persistent 64-channel kernel with precision LVAE_PREC_BF16");
   if (rc == -1000) rc = conv1x1_try(d, res, out, act, (hipStream_t)stream);
   LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
                "lvae_conv1x1_gate_f32: unsupported shape (needs a 1x1 stride-1 conv, Cin <= 128, Cout <= 128, channels %% 4 == 0, "

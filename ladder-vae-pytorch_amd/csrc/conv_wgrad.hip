@@ -521,6 +521,9 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
     const int hr = conv3x3_wgrad_bf16_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
   }
+  LVAE_REQUIRE(d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32, LVAE_EINVAL,
+               "lvae_conv2d_wgrad_f32: bf16-stored x / dy need the bf16 weight-gradient kernel, which does not take this shape "
+               "(lvae_resblock_bf16_storage(d) == 0)");
   if (!halo_off && conv_wgrad_wino_workspace(d)) {
     const int hr = conv_wgrad_wino_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;

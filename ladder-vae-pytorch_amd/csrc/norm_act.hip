@@ -2,6 +2,7 @@
 // All HBM-bound: NHWC rows of C channels are read as float4 per lane (C % 4 == 0) with consecutive lanes on
 // consecutive channels/rows, per-channel reductions go through registers -> LDS -> per-chunk partials and a
 // fixed-order finalize (no float atomics: bitwise reproducible).
+#include "bf16_frag.h"
 #include "lvae_common.h"
 
 namespace lvae {
@@ -38,6 +39,13 @@ struct Vec<4> {
   static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const F4*>(p); }
   static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<F4*>(p) = v; }
   static __device__ __forceinline__ void store_wt(float* p, T v) { store_wt4(p, f32x4{v.v[0], v.v[1], v.v[2], v.v[3]}); }
+  static __device__ __forceinline__ T load_dt(const float* base, size_t off, bool bf) {
+    const f32x4 v = load4_dt(base, off, bf);
+    return T{{v[0], v[1], v[2], v[3]}};
+  }
+  static __device__ __forceinline__ void store_dt(float* base, size_t off, T v, bool bf) {
+    store4_dt(base, off, f32x4{v.v[0], v.v[1], v.v[2], v.v[3]}, bf);
+  }
 };
 template <>
 struct Vec<1> {
@@ -45,6 +53,8 @@ struct Vec<1> {
   static __device__ __forceinline__ T load(const float* p) { return *p; }
   static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
   static __device__ __forceinline__ void store_wt(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ T load_dt(const float* base, size_t off, bool) { return base[off]; }
+  static __device__ __forceinline__ void store_dt(float* base, size_t off, T v, bool) { base[off] = v; }
 };
 template <int V>
 __device__ __forceinline__ float& at(typename Vec<V>::T& v, int j);
@@ -290,10 +300,12 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
                                                                 const float* shift, int act, const float* mean,
                                                                 const float* rstd, const float* coef,
                                                                 const float* drop, int rows_per_n,
-                                                                const float* __restrict__ add, float* __restrict__ dx) {
+                                                                const float* __restrict__ add, float* __restrict__ dx, int dtypes) {
   const int t = threadIdx.x, col = t % cols, rg = t / cols;
   if (rg >= rpp) return;
   const int c = col * V;
+  // dtypes (V == 4 only): bit 0 dh, bit 1 x, bit 2 dx stored as bf16 (lvae_affine_act_bwd_parts_f32); `add` is always fp32
+  const bool dh_bf = V == 4 && (dtypes & 1), x_bf = V == 4 && (dtypes & 2), dx_bf = V == 4 && (dtypes & 4);
   float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
   for (int j = 0; j < V; ++j) {
     sc[j] = scale ? scale[c + j] : 1.f;
@@ -312,8 +324,8 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t off = (size_t)(row + u * stride) * C + c;
-      xv[u] = Vec<V>::load(x + off);
-      gv[u] = Vec<V>::load(dh + off);
+      xv[u] = Vec<V>::load_dt(x, off, x_bf);
+      gv[u] = Vec<V>::load_dt(dh, off, dh_bf);
       if (add) av[u] = Vec<V>::load(add + off);
     }
 #pragma unroll
@@ -328,13 +340,13 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
         if (add) g += at<V>(av[u], j);
         at<V>(gv[u], j) = g;
       }
-      Vec<V>::store_wt(dx + (size_t)rw * C + c, gv[u]);
+      Vec<V>::store_dt(dx, (size_t)rw * C + c, gv[u], dx_bf);
     }
   }
   for (; row < M; row += stride) {
     const size_t off = (size_t)row * C + c;
-    typename Vec<V>::T xv = Vec<V>::load(x + off);
-    typename Vec<V>::T gv = Vec<V>::load(dh + off);
+    typename Vec<V>::T xv = Vec<V>::load_dt(x, off, x_bf);
+    typename Vec<V>::T gv = Vec<V>::load_dt(dh, off, dh_bf);
     typename Vec<V>::T av;
     if (add) av = Vec<V>::load(add + off);
     const float* dr = drop ? drop + (size_t)(row / rows_per_n) * C + c : nullptr;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
       if (add) g += at<V>(av, j);
       at<V>(gv, j) = g;
     }
-    Vec<V>::store(dx + off, gv);
+    Vec<V>::store_dt(dx, off, gv, dx_bf);
   }
 }
 
@@ -358,7 +370,8 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
                                                                      const float* scale, const float* shift, int act,
                                                                      const float* mean, const float* rstd, float* dgamma,
                                                                      float* dbeta, const float* drop, int rows_per_n,
-                                                                     const float* __restrict__ add, float* __restrict__ dx) {
+                                                                     const float* __restrict__ add, float* __restrict__ dx, int dtypes) {
+  const bool dh_bf = dtypes & 1, x_bf = dtypes & 2, dx_bf = dtypes & 4;  // storage of dh, x, dx (bf16 when set); `add` is fp32
   __shared__ float red[2][256 * 4];
   __shared__ float cf[2][256];
   const int t = threadIdx.x, col = t % cols, rg = t / cols;
@@ -373,8 +386,8 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
     for (int u = 0; u < RP; ++u) {
       const int row = row0 + u * stride;
       const size_t off = (size_t)(row < M ? row : 0) * C + c;
-      xv[u] = Vec<4>::load(x + off);
-      gv[u] = Vec<4>::load(dh + off);
+      xv[u] = Vec<4>::load_dt(x, off, x_bf);
+      gv[u] = Vec<4>::load_dt(dh, off, dh_bf);
       if (add) av[u] = Vec<4>::load(add + off);
     }
   }
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
       if (add) g += aq.v[j];
       gq.v[j] = g;
     }
-    Vec<4>::store(dx + (size_t)row * C + c, gq);
+    Vec<4>::store_dt(dx, (size_t)row * C + c, gq, dx_bf);
   };
 #pragma unroll
   for (int u = 0; u < RP; ++u) {
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
   }
   for (int row = row0 + RP * stride; row < M; row += stride) {
     const size_t off = (size_t)row * C + c;
-    const F4 xq = Vec<4>::load(x + off), gq = Vec<4>::load(dh + off);
+    const F4 xq = Vec<4>::load_dt(x, off, x_bf), gq = Vec<4>::load_dt(dh, off, dh_bf);
     F4 aq = xq;
     if (add) aq = Vec<4>::load(add + off);
     apply(row, xq, gq, aq);
@@ -692,10 +705,10 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
     const int grid = grid_for(M, rm2.rpp * 4);
     if (v4)
       hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale,
-                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx, 0);
     else
       hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale,
-                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+                         shift, act, mean, rstd, coef, drop, (int)rows_per_n, add, dx, 0);
   }
   LVAE_LAUNCH_CHECK("affine_bwd_apply");
   return 0;
@@ -704,9 +717,12 @@ extern "C" int lvae_affine_act_bwd_f32(const float* dh, const float* x, int64_t 
 extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, const float* dh, const float* x, int64_t M, int32_t C,
                                              const float* scale, const float* shift, int32_t act, const float* mean,
                                              const float* rstd, float* dgamma, float* dbeta, const float* drop, int64_t rows_per_n,
-                                             const float* add, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+                                             const float* add, float* dx, void* workspace, size_t workspace_bytes, int32_t dtypes,
+                                             void* stream) {
   LVAE_REQUIRE(parts && rows > 0 && dh && x && dx && M > 0 && C > 0 && scale && shift && mean && rstd && workspace, LVAE_EINVAL,
                "lvae_affine_act_bwd_parts_f32: bad args");
+  LVAE_REQUIRE((dtypes & ~7) == 0 && (dtypes == 0 || (C % 4 == 0 && vec_ok(C, x, dh, dx, add))), LVAE_EINVAL,
+               "lvae_affine_act_bwd_parts_f32: bf16 storage needs C %% 4 == 0 and 16-byte aligned buffers");
   LVAE_REQUIRE(workspace_bytes >= (size_t)2 * C * sizeof(float), LVAE_EWORKSPACE, "lvae_affine_act_bwd_parts_f32: workspace");
   LVAE_REQUIRE(!drop || rows_per_n > 0, LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: rows_per_n");
   LVAE_REQUIRE(M < ((int64_t)1 << 31), LVAE_EINVAL, "lvae_affine_act_bwd_parts_f32: too many rows");
@@ -715,7 +731,7 @@ extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, c
     const RowMap rm = row_map(C, 4);
     const int grid = grid_for(M, rm.rpp * 4);
     hipLaunchKernelGGL(affine_bwd_apply_parts_kernel, dim3(grid), dim3(256), 0, s, parts, rows, dh, x, (int)M, C, rm.cols, rm.rpp, scale,
-                       shift, act, mean, rstd, dgamma, dbeta, drop, (int)rows_per_n, add, dx);
+                       shift, act, mean, rstd, dgamma, dbeta, drop, (int)rows_per_n, add, dx, (int)dtypes);
     LVAE_LAUNCH_CHECK("affine_bwd_apply_parts");
     return 0;
   }
@@ -728,10 +744,10 @@ extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, c
   const int grid = grid_for(M, rm2.rpp * 4);
   if (v4)
     hipLaunchKernelGGL(affine_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale, shift,
-                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx, (int)dtypes);
   else
     hipLaunchKernelGGL(affine_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, s, dh, x, (int)M, C, rm2.cols, rm2.rpp, scale, shift,
-                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx);
+                       act, mean, rstd, coef, drop, (int)rows_per_n, add, dx, 0);
   LVAE_LAUNCH_CHECK("affine_bwd_apply");
   return 0;
 }

@@ -112,17 +112,20 @@ def prior_samples(model, n_imgs):
 
 
 @torch.no_grad()
-def inspect_layer_repr(model, n_imgs=8):
-    """evaluate.py:95-114: for every layer i, samples with layers below i at their mode and layers above i held constant
-    across the batch — what varies shows what layer i encodes. Returns a list of (n, C, H, W) tensors."""
+def inspect_layer_repr(model, n=8):
+    """evaluate.py:95-114: for every layer i, n calls of `sample_prior(n, mode_layers=range(i), constant_layers=range(i+1, L))`
+    concatenated — each call (one row of the reference's image grid) draws the layers above i once for its whole batch, samples
+    layer i per image and takes the mode below, so a row shows what layer i encodes. Returns a list of L tensors (n*n, C, H, W);
+    the reference writes each as a PNG grid with nrow = n (image files are out of scope)."""
     was_training = model.training
     model.eval()
     try:
         out = []
         for i in range(model.n_layers):
-            mode_layers = list(range(i))
-            constant_layers = list(range(i + 1, model.n_layers))
-            out.append(model.sample_prior(n_imgs, mode_layers=mode_layers, constant_layers=constant_layers))
+            mode_layers = range(i)
+            constant_layers = range(i + 1, model.n_layers)
+            rows = [model.sample_prior(n, mode_layers=mode_layers, constant_layers=constant_layers) for _ in range(n)]
+            out.append(torch.cat(rows))
         return out
     finally:
         model.train(was_training)

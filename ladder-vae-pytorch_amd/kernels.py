@@ -39,8 +39,9 @@ class use_form:
 
 
 BF16_MODE_NOTE = ('forward, dgrad and weight gradient of the 3x3 convolutions of the 8x8..32x32 levels and the GateLayer2d 1x1 family on '
-                  'v_mfma_f32_32x32x16_bf16 with bf16 operands; fp32 accumulate / statistics / KL / likelihood; merge 1x1 and <=4x4 '
-                  'convolutions fp32')
+                  'v_mfma_f32_32x32x16_bf16 with bf16 operands; the tensors inside those residual blocks (conv outputs, gate pre-activations '
+                  'and their gradients) stored as bf16 in HBM, as torch.autocast(bfloat16) stores conv outputs; residual stream, fp32 '
+                  'accumulate / statistics / KL / likelihood / parameters / Adamax; merge 1x1 and <=4x4 convolutions fp32')
 
 
 def set_precision(dtype):
@@ -59,9 +60,14 @@ def workspace(nbytes, device):
 
 
 def _chk_nhwc(t, name):
-    if t.dim() != 4 or not t.is_contiguous() or t.dtype != torch.float32:
-        raise _C.LvaeHipError("%s must be a contiguous float32 (N,H,W,C) tensor, got shape %s strides %s %s" %
-                              (name, tuple(t.shape), tuple(t.stride()), t.dtype))
+    if t.dim() != 4 or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
+        raise _C.LvaeHipError("%s must be a contiguous float32 (or, inside a residual block under compute_dtype bf16, bfloat16) (N,H,W,C) "
+                              "tensor, got shape %s strides %s %s" % (name, tuple(t.shape), tuple(t.stride()), t.dtype))
+
+
+def _dt(t):
+    """lvae_conv_desc.*_dtype of a tensor (LVAE_DT_F32 for None)."""
+    return _C.DT_BF16 if (t is not None and t.dtype == torch.bfloat16) else _C.DT_F32
 
 
 class ConvGeom:
@@ -105,6 +111,9 @@ def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, b
     d.KH, d.KW, d.stride, d.pad, d.gather = g.KH, g.KW, g.stride, g.pad, gather
     d.precision = precision
     d.form = form
+    d.x_dtype, d.y_dtype = _dt(x), _dt(y)
+    if x2 is not None and x2.dtype != x.dtype:
+        raise _C.LvaeHipError("x and x2 must have the same element type")
     return d
 
 
@@ -210,6 +219,18 @@ def _conv_ws(d, weight, device):
         prepared.attach(d, weight, device, need)
 
 
+def resblock_bf16_storage(x, weight, g):
+    """True when a residual block whose 3x3 convolutions are (weight, g) on input x can keep its internal tensors (conv outputs, gate
+    pre-activations and their gradients) in bf16: precision bf16 and every kernel of the block's forward and backward has the
+    bf16-storage form for this shape (lvae_resblock_bf16_storage)."""
+    if precision != PREC_BF16 or _ddi is not None or x.dtype != torch.float32:
+        return False
+    N, H, W, _ = x.shape
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV)
+    _conv_ws(d, weight, x.device)
+    return bool(_C.load().lvae_resblock_bf16_storage(C.byref(d)))
+
+
 _ddi = None  # set by init.data_dependent_init for the duration of its forward pass
 
 
@@ -252,14 +273,15 @@ class StatParts:
 
 
 def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_act=None, out_scale=None, out_act=None,
-           stats_pivot=None, in_bn=None):
+           stats_pivot=None, in_bn=None, out_bf16=False):
     """y = out_act((conv(in_act(x*in_scale+in_shift)) + bias) * out_scale). x (and x2) NHWC; returns NHWC.
     stats_pivot (Cout,): also ask the kernel's epilogue for BatchNorm partials of y around that pivot; returns (y, parts) with
     parts a StatParts, or (y, None) when the kernel variant chosen for this shape has no such epilogue.
     in_bn = (parts: StatParts, pivot, bn): training-mode BatchNorm of the INPUT whose statistics exist as partial sums (bn has
     weight, bias, running_mean, running_var, eps, momentum); the coefficients are finalized inside the convolution when the
     selected kernel can do that (lvae_conv2d_folds_bn_finalize) and by lvae_bn_finalize_parts_f32 otherwise. Returns
-    (y, parts | None, (scale, shift, mean, rstd))."""
+    (y, parts | None, (scale, shift, mean, rstd)).
+    out_bf16: store y as bfloat16 (only inside a residual block whose shape passed resblock_bf16_storage)."""
     if _ddi is not None and weight.data_ptr() not in _ddi['done']:
         assert in_bn is None
         y = _ddi_conv(_ddi, x, weight, g, bias, x2, in_scale, in_shift, in_act, out_scale, out_act)
@@ -272,7 +294,7 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     if C1 + (x2.shape[3] if x2 is not None else 0) != g.Cin:
         raise _C.LvaeHipError("conv2d: input has %d channels, weight expects %d" % (C1 + (x2.shape[3] if x2 is not None else 0), g.Cin))
     OH, OW = g.out_size(H, W)
-    y = torch.empty((N, OH, OW, g.Cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((N, OH, OW, g.Cout), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, out_act, y)
     _conv_ws(d, weight, x.device)
@@ -319,7 +341,7 @@ def conv1x1_gate(x, weight, g, bias, res, act, need_ab=True, stats_pivot=None):
         ab = conv2d(x, weight, g, bias=bias)
         out = gate_fwd(ab, res, act)
         return (ab, out) if stats_pivot is None else (ab, out, None)
-    ab = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=x.device) if need_ab else None
+    ab = torch.empty((N, H, W, g.Cout), dtype=x.dtype, device=x.device) if need_ab else None   # bf16-stored x: bf16-stored ab
     out = torch.empty((N, H, W, Cn), dtype=torch.float32, device=x.device)
     d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV, bias, y=ab)
     parts = None
@@ -350,7 +372,7 @@ def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):
     return dab, dx
 
 
-def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scale=None):
+def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scale=None, out_bf16=False):
     """conv1x1_gate_bwd and the weight / bias gradient of the gate convolution in one persistent kernel (dab never leaves LDS):
     returns dx, and accumulates into dweight / dbias. Returns None when the shape is not supported (caller composes the two)."""
     _chk_nhwc(dout, 'dout')
@@ -359,7 +381,9 @@ def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scal
         return None
     if tuple(dweight.stride()) != tuple(weight.stride()):
         return None
-    dx = torch.empty((N, H, W, g.Cin), dtype=torch.float32, device=dout.device)
+    if ab.dtype != y.dtype:
+        raise _C.LvaeHipError("conv1x1_gate_bwd_wgrad: ab and y must have the same element type")
+    dx = torch.empty((N, H, W, g.Cin), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dout.device)
     d = _desc(g, weight, ab, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     need = _C.load().lvae_conv1x1_gate_bwd_wgrad_workspace(C.byref(d))
     if not need:
@@ -379,21 +403,22 @@ def bn_coef_block(scale, shift, mean, rstd):
     return shift.data_ptr() == p0 + n and mean.data_ptr() == p0 + 2 * n and rstd.data_ptr() == p0 + 3 * n
 
 
-def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, dbeta, drop=None, add=None):
+def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, dbeta, drop=None, add=None, out_bf16=False):
     """affine_act_bwd (training-mode BatchNorm) with the reduction already done by the epilogue of the convolution that produced dh
     (conv2d_dgrad(..., bn_bwd=...))."""
     Cn = x.shape[-1]
     M = x.numel() // Cn
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     ws = workspace(8 * Cn, x.device)
     rows_per_n = M // x.shape[0]
+    dtypes = _dt(dh) | (_dt(x) << 1) | (_dt(dx) << 2)
     call('lvae_affine_act_bwd_parts_f32', ptr(parts), parts.shape[0], ptr(dh), ptr(x), M, Cn, ptr(scale), ptr(shift), ACT[act],
          ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(drop), rows_per_n, ptr(add), ptr(dx), ws.data_ptr(), ws.numel(),
-         stream_ptr())
+         dtypes, stream_ptr())
     return dx
 
 
-def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=None):
+def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=None, out_bf16=False):
     """Gradient w.r.t. the conv input (before any fused input transform). dy NHWC (N,OH,OW,Cout) -> (N,H,W,Cin).
     out_scale (N,Cin) multiplies the result per (sample, channel) (Dropout2d mask of the producer).
     ci_range=(a,b) restricts the result to input channels [a,b) (the two halves of a fused channel concat)."""
@@ -401,7 +426,7 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=Non
     N, OH, OW, Co = dy.shape
     H, W = in_hw
     a, b = ci_range if ci_range is not None else (0, g.Cin)
-    dx = torch.empty((N, H, W, b - a), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((N, H, W, b - a), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dy.device)
     d = _desc(g, weight, dy, None, N, OH, OW, H, W, b - a, g.s_co, g.s_ci,
               GATHER_CONV if g.transposed else GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     d.w = ptr(weight) + 4 * a * g.s_ci
@@ -417,7 +442,7 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=Non
     if rows > 0 and out_scale is None and ci_range is None and tuple(xb.shape) == tuple(dx.shape):
         parts = torch.empty((rows, 2, b - a), dtype=torch.float32, device=dy.device)
         d.stats_out, d.stats_pivot, d.stats_x = ptr(parts), ptr(coef), ptr(xb)
-        d.stats_mode, d.stats_act = 1, ACT[act]
+        d.stats_mode, d.stats_act, d.stats_x_dtype = 1, ACT[act], _dt(xb)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return dx, parts
 
@@ -434,6 +459,7 @@ def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, 
                               (tuple(dweight.stride()), tuple(weight.stride())))
     d = _desc(g, weight, x, x2, N, H, W, OH, OW, g.Cout, g.s_ci, g.s_co,
               GATHER_TRANSPOSED if g.transposed else GATHER_CONV, None, in_scale, in_shift, in_act)
+    d.y_dtype = _dt(dy)
     need = _C.load().lvae_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
     call('lvae_conv2d_wgrad_f32', C.byref(d), ptr(dy), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())
@@ -454,6 +480,7 @@ def conv2d_wgrad_grouped(items):
         N, H, W, _ = x.shape
         d = _desc(g, weight, x, kw.get('x2'), N, H, W, dy.shape[1], dy.shape[2], g.Cout, g.s_ci, g.s_co,
                   GATHER_TRANSPOSED if g.transposed else GATHER_CONV, None, kw.get('in_scale'), kw.get('in_shift'), kw.get('in_act'))
+        d.y_dtype = _dt(dy)
         C.memmove(C.byref(descs, i * C.sizeof(ConvDesc)), C.byref(d), C.sizeof(ConvDesc))
         dys[i], dws[i], dbs[i] = ptr(dy), ptr(dweight), ptr(dbias)
     need = _C.load().lvae_conv2d_wgrad_grouped_workspace(descs, n)

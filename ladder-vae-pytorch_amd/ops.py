@@ -170,6 +170,10 @@ class ResBlockFn(Function):
         # BatchNorm partials of h written by the epilogue of the kernel that produced it: for x by the previous block's gate
         # kernel (handed over through blk._in_parts by lib/nn.py), for conv1's output by conv1 itself
         parts, pivot_in = blk.__dict__.pop('_in_parts', None) or (None, None)
+        # compute_dtype bf16: conv outputs and gate pre-activations of the block (and, in backward, their gradients) live in bf16 where
+        # every kernel involved has that form; the block's input / output (the residual stream) stay fp32
+        s16 = (blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
+               (training or not torch.is_grad_enabled()) and K.resblock_bf16_storage(x, blk.conv1.weight, blk.conv1.geom()))
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
             want_stats = training and nxt is not None and nxt.running_mean is not None
@@ -177,7 +181,7 @@ class ResBlockFn(Function):
                 # statistics of h exist as partial sums: finalized inside the convolution where the kernel can (<= 4x4 levels)
                 y, parts_out, (sc, sh, mean, rstd) = K.conv2d(
                     h, cv.weight, cv.geom(), bias=cv.bias, in_act=act, out_scale=m, in_bn=(parts, pivot_in if i == 0 else bn.running_mean, bn),
-                    stats_pivot=nxt.running_mean if want_stats else None)
+                    stats_pivot=nxt.running_mean if want_stats else None, out_bf16=s16)
             else:
                 if bn is not None:
                     if training:
@@ -190,9 +194,10 @@ class ResBlockFn(Function):
                     mean = rstd = None
                 if want_stats:
                     y, parts_out = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m,
-                                            stats_pivot=nxt.running_mean)
+                                            stats_pivot=nxt.running_mean, out_bf16=s16)
                 else:
-                    y, parts_out = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m), None
+                    y, parts_out = K.conv2d(h, cv.weight, cv.geom(), bias=cv.bias, in_scale=sc, in_shift=sh, in_act=act, out_scale=m,
+                                            out_bf16=s16), None
             parts = parts_out
             st.append((h, sc, sh, mean, rstd))
             h = y
@@ -212,7 +217,7 @@ class ResBlockFn(Function):
                 ab, out = K.conv1x1_gate(y2, blk.gate.weight, blk.gate.geom(), blk.gate.bias, x, act)
         else:
             out = K.add(y2, x)
-        ctx.blk, ctx.training = blk, training
+        ctx.blk, ctx.training, ctx.s16 = blk, training, s16
         (x0, sc1, sh1, mean1, rstd1), (y1, sc2, sh2, mean2, rstd2) = st
         ctx.save_for_backward(x0, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2)
         return out
@@ -224,13 +229,17 @@ class ResBlockFn(Function):
         x, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2 = ctx.saved_tensors
         dout = _c(dout)
         hw = (x.shape[1], x.shape[2])
+        s16 = ctx.s16   # bf16-stored block internals: every launch below then has to take the bf16-storage kernel (it raises otherwise)
         if blk.gate is not None:
             gw = blk.gate.weight
             dy2 = None
             if gw.requires_grad and blk.gate.bias is not None:
                 # large levels: gate derivative, dgrad and the gate convolution's weight gradient in one persistent kernel
-                dy2 = K.conv1x1_gate_bwd_wgrad(dout, ab, y2, gw, blk.gate.geom(), act, grad_buf(gw), grad_buf(blk.gate.bias), out_scale=m2)
+                dy2 = K.conv1x1_gate_bwd_wgrad(dout, ab, y2, gw, blk.gate.geom(), act, grad_buf(gw), grad_buf(blk.gate.bias), out_scale=m2,
+                                               out_bf16=s16)
             if dy2 is None:
+                if s16:
+                    raise K._C.LvaeHipError("bf16-stored residual block: the fused gate backward did not take this shape")
                 dab, dy2 = K.conv1x1_gate_bwd(dout, ab, gw, blk.gate.geom(), act, out_scale=m2)
                 wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
         else:
@@ -242,12 +251,12 @@ class ResBlockFn(Function):
         train2 = bn2 is not None and ctx.training
         parts2 = None
         if train2 and K.bn_coef_block(sc2, sh2, mean2, rstd2):  # BatchNorm-backward sums in the dgrad kernel's epilogue
-            dh2, parts2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw, bn_bwd=(y1, sc2, act))
+            dh2, parts2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw, bn_bwd=(y1, sc2, act), out_bf16=s16)
         else:
             dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
         if parts2 is not None:
             dy1 = K.affine_act_bwd_parts(parts2, dh2, y1, sc2, sh2, act, mean2, rstd2, grad_buf(bn2.weight), grad_buf(bn2.bias),
-                                         drop=m1)
+                                         drop=m1, out_bf16=s16)
         else:
             dy1 = K.affine_act_bwd(dh2, y1, sc2, sh2, act, train2, mean2, rstd2,
                                    grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
@@ -258,7 +267,7 @@ class ResBlockFn(Function):
         train1 = bn1 is not None and ctx.training
         parts1 = None
         if train1 and K.bn_coef_block(sc1, sh1, mean1, rstd1):
-            dh1, parts1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw, bn_bwd=(x, sc1, act))
+            dh1, parts1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw, bn_bwd=(x, sc1, act), out_bf16=s16)
         else:
             dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
         if parts1 is not None:

@@ -507,6 +507,17 @@ def sample_prior(sd, cfg, n_imgs, tape, mode_layers=None, constant_layers=None, 
     return info['sample']
 
 
+def inspect_layer_repr(sd, cfg, tape, n=8):
+    """evaluate.py:95-114 without the image files: per layer i, n calls of sample_prior(n, mode_layers=range(i),
+    constant_layers=range(i + 1, n_layers)) concatenated (the rows of the reference's nrow = n grid). Returns a list of n_layers tensors."""
+    L = len(cfg['z_dims'])
+    out = []
+    for i in range(L):
+        rows = [sample_prior(sd, cfg, n, tape, mode_layers=range(i), constant_layers=range(i + 1, L)) for _ in range(n)]
+        out.append(torch.cat(rows))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # experiment/experiment_manager.py
 # --------------------------------------------------------------------------------------------------

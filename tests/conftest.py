@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _default_kernel_arithmetic():
+    """kernels.precision / kernels.form are module-level requests that a model's forward pass (compute_dtype) or a test may have left
+    behind: every test starts from the product defaults (fp32, LVAE_FORM_AUTO)."""
+    mod = sys.modules.get('lvae_amd.kernels')
+    if mod is not None:
+        mod.precision, mod.form = mod.PREC_F32, mod._C.FORM_AUTO
+    yield
+
+
 class Golden:
     """One tests/golden/<name>.npz: dotted keys regrouped into lists / dicts."""
 

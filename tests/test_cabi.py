@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
         decl = decl.strip()
         if not decl or decl.startswith('typedef'):
             continue
-        decl = decl.replace('const struct lvae_bn_fold*', '').replace('const float*', '').replace('float*', '').replace('void*', '').replace('int32_t', '').replace('int64_t', '')
+        decl = decl.replace('const struct lvae_bn_fold*', '').replace('const float*', '').replace('float*', '').replace('void*', '').replace('int32_t', '').replace('int64_t', '').replace('uint8_t', '')
         names += [n.strip() for n in decl.split(',') if n.strip()]
     assert names == [f[0] for f in ConvDesc._fields_]
 

@@ -123,11 +123,12 @@ def test_fused_gate_backward_forms_agree_on_random_shapes(K):
 #   * Winograd F(2x2,3x3) — either form — forms +-combinations of the 4x4 input block of a tile before multiplying, so ONE non-finite
 #     input makes every output of every tile whose 4x4 block contains it non-finite (inf - inf = NaN already in the fp32 transform);
 #     outputs of all other tiles are bit-identical to the run without it.
-#   * the six-product split turns |v| beyond the bf16 range (> 3.396e38: rounds to bf16 infinity) into NaN, where an fp32 product would be
-#     finite or +-inf; 3.39e38 (below bf16 max + half an ulp) stays finite and exact.
+#   * the six-product split turns an INFINITE operand into NaN (inf - inf in the remainder), where an fp32 product would be +-inf;
+#     finite operands of any magnitude keep their fp32 result, also beyond the bf16 range (3.39e38 .. FLT_MAX: measured on gfx950, the
+#     f32 -> bf16 conversion does not overflow there and the remainder pieces carry the rest).
 #   * denormal operands: products of pieces far below FLT_MIN; results stay finite and within 1e-37 (absolute) of the clean result.
 # ------------------------------------------------------------------------------------------------------------------------------------
-SPECIALS = [float('inf'), float('-inf'), float('nan'), 3.4e38]
+SPECIALS = [float('inf'), float('-inf'), float('nan')]
 
 
 @pytest.mark.parametrize('form', ['f32_mfma', 'six'])
@@ -155,17 +156,14 @@ def test_winograd_non_finite_operand_stays_inside_its_tiles(K, form, special):
     assert torch.equal(out[~touched], clean[~touched]), 'a special operand leaked outside the Winograd tiles that contain it'
     field = torch.zeros(N, H, W, dtype=torch.bool, device='cuda')
     field[n0, max(0, h0 - 1):h0 + 2, max(0, w0 - 1):w0 + 2] = True      # the 3x3 receptive fields that really use the pixel
-    if special == 3.4e38 and form == 'f32_mfma':
-        # fp32 arithmetic: 3.4e38 * w (|w| ~ 0.04) is finite; sums inside the transform may overflow to inf but never to NaN by themselves
-        pass
-    else:
-        assert not torch.isfinite(out[field]).all(dim=-1).any(), 'outputs that use the special operand must be non-finite'
+    assert not torch.isfinite(out[field]).all(dim=-1).any(), 'outputs that use the special operand must be non-finite'
 
 
 @pytest.mark.parametrize('form', ['f32_mfma', 'six'])
 def test_winograd_large_finite_and_denormal_operands(K, form):
-    """3.39e38 is below bf16 max + half an ulp: the six-product split keeps it exact (pieces 3.3895e38 + 4.6e34 + ...), so with weights
-    small enough that no fp32 sum overflows the result matches float64; denormal inputs give finite results within 1e-37 of the clean run."""
+    """Finite operands beyond the bf16 range (bf16 max = 3.3895e38 < 3.4e38 < FLT_MAX): both forms must give the fp32 result (weights
+    small enough that no fp32 sum overflows); denormal inputs give finite results equal to float64 to fp32 accuracy, and do not disturb
+    any other tile."""
     torch.manual_seed(10)
     N, H, W, C = 70, 16, 16, 64
     x = torch.randn(N, H, W, C, device='cuda')
@@ -175,7 +173,7 @@ def test_winograd_large_finite_and_denormal_operands(K, form):
         K.prepared.entries.clear()
         K.prepared.table = None
         xs = x.clone()
-        xs[3, 8, 8, 5] = 3.39e38 / 8          # the input transform adds up to 4 block entries: stay below FLT_MAX
+        xs[3, 8, 8, 5] = 3.4e38               # one huge entry per 4x4 block: the +-combinations of the input transform stay below FLT_MAX
         out = K.conv2d(xs, w, g)
         ref = torch.nn.functional.conv2d(xs.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
         assert torch.isfinite(out).all()
@@ -216,7 +214,28 @@ def test_fused_gate_backward_non_finite_operand(K, special):
             rows = torch.ones(N, H, H, dtype=torch.bool, device='cuda')
             rows[6, 3, 4] = False
             assert torch.equal(dx[rows], clean[rows])
-            if special == 3.4e38 and f == K._C.FORM_F32_MFMA:
-                continue    # finite in fp32 arithmetic
             assert not torch.isfinite(dx[6, 3, 4]).all()
             assert not torch.isfinite(db2[17]) or not torch.isfinite(db2[17 + C])
+
+
+def test_fused_gate_backward_operand_beyond_bf16_range(K):
+    """3.4e38 in dout (finite in fp32, beyond bf16 max): both forms give finite dx rows equal to the float64 product to fp32 accuracy."""
+    torch.manual_seed(12)
+    N, H, C = 70, 16, 64
+    dout = torch.randn(N, H, H, C, device='cuda')
+    ab = torch.randn(N, H, H, 2 * C, device='cuda')
+    y = torch.randn(N, H, H, C, device='cuda')
+    w = packed(2 * C, C, 1) * 1e-2
+    g = K.ConvGeom(w, 1, 0)
+    dout[6, 3, 4, 17] = 3.4e38
+    a_, b_ = ab[6, 3, 4, :C].double(), ab[6, 3, 4, C:].double()
+    sig = torch.sigmoid(b_)
+    da = dout[6, 3, 4].double() * sig * torch.where(a_ > 0, torch.ones_like(a_), a_.exp())
+    db_ = dout[6, 3, 4].double() * torch.nn.functional.elu(a_) * sig * (1 - sig)
+    ref = torch.cat([da, db_]) @ w[:, :, 0, 0].double()       # dx[m, ci] = sum_co dab[m, co] * W[co, ci]
+    for f in (K._C.FORM_F32_MFMA, K._C.FORM_AUTO):
+        with K.use_form(f):
+            dw, db = torch.zeros_like(w), torch.zeros(2 * C, device='cuda')
+            dx = K.conv1x1_gate_bwd_wgrad(dout, ab, y, w, g, 'elu', dw, db)
+            assert torch.isfinite(dx).all()
+            assert rel(dx[6, 3, 4].double(), ref) < 1e-5

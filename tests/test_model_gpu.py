@@ -194,10 +194,29 @@ def test_iw_log_likelihood_with_bottom_up_reuse_matches_oracle():
     torch.testing.assert_close(iw.cpu(), iw_ref, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(elbo.cpu(), elbo_ref, rtol=1e-5, atol=1e-4)
     assert float((iw.cpu() - elbo.cpu()).min()) >= -1e-3   # Jensen: the IW bound is at least the mean ELBO
-    from lvae_amd.noise import PhiloxNoise
-    m.noise = PhiloxNoise(seed=1)
-    reps = inspect_layer_repr(m, 4)
-    assert len(reps) == m.n_layers and tuple(reps[0].shape) == (4, 3, 32, 32)
+
+
+def test_inspect_layer_repr_matches_oracle():
+    """evaluate.py:95-114: per layer, n rows of n images (n sample_prior calls with the layers below at their mode and the layers above
+    constant within a call), against the oracle's restatement on the same noise tape."""
+    from oracle import lvae_ref as R
+    from lvae_amd.evaluate import inspect_layer_repr
+    g = load_golden('tiny_cifar')
+    n = 3
+    tape = R.Tape(gen=torch.Generator().manual_seed(8))
+    ref = R.inspect_layer_repr(g.state_dict(), g.cfg, tape, n)
+    m, TapeNoise = build(g, training=True)   # switches to eval itself and restores the mode
+    m.noise = TapeNoise(tape.entries)
+    reps = inspect_layer_repr(m, n)
+    assert m.noise.exhausted() and m.training
+    assert len(reps) == m.n_layers == len(ref)
+    for a, b in zip(reps, ref):
+        assert tuple(a.shape) == (n * n, 3, 32, 32) == tuple(b.shape)
+        torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=2e-4)
+    # within a row the constant layers were drawn once: with every layer but the top one at its mode (i = L - 1 has no constant
+    # layer) rows differ; for i = 0 all layers above are constant per row, so images of a row share everything but layer 0
+    top = reps[0].view(n, n, *reps[0].shape[1:])
+    assert float((top[0] - top[1]).abs().max()) > 1e-3
 
 
 def test_checkpoint_roundtrip_and_cli(tmp_path):
@@ -323,6 +342,63 @@ def test_data_dependent_init_is_a_fixed_point_after_one_pass():
     out = model(x)                           # the product path still runs after the in-place updates
     assert torch.isfinite(out['ll']).all()
 
+
+
+def test_data_dependent_init_normalises_every_convolution_output():
+    """--data-dep-init (parity unpinned: boilr absent, no fixture can exist offline). Property of the algorithm as the reference's call
+    site describes it (experiment/experiment_manager.py:61-72 -> boilr.nn.init.data_dependent_init): after the pass, on the SAME batch
+    and noise, the output of every convolution — visited in execution order, each seeing the corrected outputs of its predecessors —
+    has per-channel mean 0 and standard deviation 1. Checked in float64 on the tensors the HIP convolutions really produce."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd import kernels as K
+    from lvae_amd.init import data_dependent_init
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import PhiloxNoise
+    cfg = dict(color_ch=3, z_dims=[8, 8, 8], blocks_per_layer=2, downsample=[0, 1, 1], nonlin='elu', merge_type='residual',
+               batchnorm=True, stochastic_skip=True, n_filters=32, dropout=0.0, free_bits=0.5, learn_top_prior=True,
+               img_shape=(32, 32), likelihood_form='discr_log_mix', res_block_type='bacdbacd', gated=True,
+               no_initial_downscaling=False, analytical_kl=False)
+    torch.manual_seed(6)
+    model = LadderVAE(**cfg).cuda().train()
+    model.pack()
+    x = (torch.floor(256 * torch.rand(64, 3, 32, 32)) / 255).cuda()
+    model.noise = PhiloxNoise(seed=4)
+    n = data_dependent_init(model, x)
+    seen = []
+    orig_conv2d, orig_gate = K.conv2d, K.conv1x1_gate
+
+    def note(y):
+        y64 = y.detach().double().reshape(-1, y.shape[-1])
+        seen.append((float(y64.mean(0).abs().max()), float((y64.std(0, unbiased=False) - 1).abs().max())))
+
+    def conv2d(x_, weight, g, **kw):
+        if kw.get('out_scale') is None and kw.get('out_act') is None:
+            r = orig_conv2d(x_, weight, g, **kw)
+            note(r[0] if isinstance(r, tuple) else r)
+            return r
+        plain = {k: v for k, v in kw.items() if k in ('bias', 'x2', 'in_scale', 'in_shift', 'in_act')}
+        if 'in_bn' not in kw:   # (a folded BatchNorm finalize has no plain twin; its output is checked through the epilogue-free calls)
+            note(orig_conv2d(x_, weight, g, **plain))
+        return orig_conv2d(x_, weight, g, **kw)
+
+    def gate(x_, weight, g, bias, res, act, **kw):
+        r = orig_gate(x_, weight, g, bias, res, act, **kw)
+        if r[0] is not None:
+            note(r[0])            # ab = the gate convolution's output
+        return r
+
+    K.conv2d, K.conv1x1_gate = conv2d, gate
+    try:
+        model.noise = PhiloxNoise(seed=4)
+        with torch.no_grad():
+            model(x)
+    finally:
+        K.conv2d, K.conv1x1_gate = orig_conv2d, orig_gate
+    assert len(seen) >= n - 2 and n > 20, (len(seen), n)
+    worst_mean = max(m for m, _ in seen)
+    worst_std = max(sd for _, sd in seen)
+    assert worst_mean < 1e-4, worst_mean
+    assert worst_std < 1e-3, worst_std
 
 
 def test_iw_log_likelihood_graph_replay_matches_eager_loop():
