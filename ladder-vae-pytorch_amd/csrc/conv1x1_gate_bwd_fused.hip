@@ -197,8 +197,11 @@ constexpr int GBB_LDA = 136;  // dab row pitch in bf16 (128 channels + 8: 272 by
 constexpr int GBB_LDY = 72;   // y row pitch in bf16
 constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4; }
 
-template <int SPLIT>
+// S16 (SPLIT == 1): ab, y and dx are bf16-stored (residual-block internals under compute_dtype bf16) and move as 16-byte pieces: a thread
+// takes 8 channels of ONE pixel row per tile (5 loads of 16 bytes instead of 8, one 16-byte store instead of two of 8).
+template <int SPLIT, bool S16 = false>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
+  static_assert(SPLIT == 1 || !S16, "bf16 storage exists for the bf16-operand form only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int A_PLANE = 64 * GBB_LDA, Y_PLANE = 64 * GBB_LDY;
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [SPLIT][64 px][136]: dab tile
@@ -224,11 +227,23 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
     }
   }
 
-  constexpr int IT = 2;
-  f32x4 pg[IT], pa[IT], pb[IT], py[IT];
+  constexpr int IT = S16 ? 1 : 2;
+  f32x4 pg[2], pa[IT], pb[IT], py[IT];
+  bf16x8 qa, qb, qy;   // S16: ab[c8 .. c8 + 7], ab[64 + c8 ..], y[c8 ..] of row r8
   const int c4 = (t & 15) * 4, r0 = t >> 4;
+  const int c8 = (t & 7) * 8, r8 = t >> 3;
   auto prefetch = [&](int tile) {
     const int m0 = tile * 64;
+    if (S16) {
+      const int m = m0 + r8;
+      const size_t mc = m < a.M ? (size_t)m : 0;
+      pg[0] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c8);
+      pg[1] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c8 + 4);
+      qa = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.ab) + mc * 128 + c8);
+      qb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.ab) + mc * 128 + 64 + c8);
+      qy = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.y) + mc * 64 + c8);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int m = m0 + r0 + 32 * u;
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
   f32x4 bs_lo = zero4, bs_hi = zero4;  // bias-gradient partials (fp32 dab, not the rounded operand)
+  f32x4 bs_lo8 = zero4, bs_hi8 = zero4;  // S16: channels c8 + 4 .. c8 + 7
   // transposed-read addresses of this lane (bf16_frag.h): pixel row 8 (G >> 1) + (i16 >> 2) of a k-step, channel 16 (G & 1) + 4 (i16 & 3) of a block
   const int trow = 8 * (G >> 1) + (i16 >> 2), tch = 16 * (G & 1) + 4 * (i16 & 3);
   // piece products in ascending order of magnitude: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); SPLIT = 1: the single product
@@ -257,6 +273,29 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
     const int m0 = tile * 64;
+    if (S16) {
+      f32x4 lo[2] = {zero4, zero4}, hi[2] = {zero4, zero4};
+      bf16x8 yv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m0 + r8 < a.M) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float av = (float)qa[4 * h + j], bv = (float)qb[4 * h + j];
+            const float sg = sigmoidf_(bv);
+            lo[h][j] = pg[h][j] * sg * act_grad(av, a.act);
+            hi[h][j] = pg[h][j] * act_fwd(av, a.act) * sg * (1.f - sg);
+          }
+        yv = qy;
+      }
+      bs_lo += lo[0];
+      bs_lo8 += lo[1];
+      bs_hi += hi[0];
+      bs_hi8 += hi[1];
+      *reinterpret_cast<bf16x8*>(As + r8 * GBB_LDA + c8) = to_bf16x8(lo[0], lo[1]);
+      *reinterpret_cast<bf16x8*>(As + r8 * GBB_LDA + 64 + c8) = to_bf16x8(hi[0], hi[1]);
+      *reinterpret_cast<bf16x8*>(Ys + r8 * GBB_LDY + c8) = yv;
+    } else
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int r = r0 + 32 * u;
@@ -326,6 +365,18 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       }
     }
     __syncthreads();  // dab / y tiles are dead (the next iteration overwrites them), the dx staging tile is complete
+    if (S16) {
+      const int m = m0 + r8;
+      if (m < a.M) {
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(Os + r8 * GB_LDY + c8), v1 = *reinterpret_cast<const f32x4*>(Os + r8 * GB_LDY + c8 + 4);
+        if (a.drop) {
+          v0 = v0 * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c8);
+          v1 = v1 * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c8 + 4);
+        }
+        const bf16x8 o = to_bf16x8(v0, v1);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(reinterpret_cast<__bf16*>(a.dx) + (size_t)m * 64 + c8), "v"(o) : "memory");
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int r = r0 + 32 * u, m = m0 + r;
@@ -348,6 +399,21 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
   }
   if (a.slab_b) {
     __syncthreads();  // the last tile's dx staging reads are done
+    if (S16) {
+      float* red = reinterpret_cast<float*>(smem_raw);  // [64 row groups][128] floats = 32 KB <= the 43 KB of the three tiles
+      *reinterpret_cast<f32x4*>(red + r8 * 128 + c8) = bs_lo;
+      *reinterpret_cast<f32x4*>(red + r8 * 128 + c8 + 4) = bs_lo8;
+      *reinterpret_cast<f32x4*>(red + r8 * 128 + 64 + c8) = bs_hi;
+      *reinterpret_cast<f32x4*>(red + r8 * 128 + 64 + c8 + 4) = bs_hi8;
+      __syncthreads();
+      if (t < 128) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 64; ++g) v += red[g * 128 + t];
+        a.slab_b[(size_t)blockIdx.x * 128 + t] = v;
+      }
+      return;
+    }
     float* red = Os;  // [32 row groups][128] floats = 16 KB <= the 17 KB staging tile
     *reinterpret_cast<f32x4*>(red + r0 * 128 + c4) = bs_lo;
     *reinterpret_cast<f32x4*>(red + r0 * 128 + 64 + c4) = bs_hi;
@@ -416,11 +482,12 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
   }
   const bool f32_mfma = d->form == LVAE_FORM_F32_MFMA;  // default for fp32: the six-product form on the bf16 MFMA
   if (d->precision == LVAE_PREC_BF16) {
-    hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel<1>, dim3(nwg), dim3(512), gbb_lds(1), s, a);
+    if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, false>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
   } else if (!f32_mfma) {
     static std::atomic<bool> attr3_set{false};
     if (!attr3_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
       if (e != hipSuccess) {
         set_error("conv1x1_gate_bwd_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -428,7 +495,7 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
       }
       attr3_set = true;
     }
-    hipLaunchKernelGGL(conv1x1_gate_bwd_fused_bf16_kernel<3>, dim3(nwg), dim3(512), gbb_lds(3), s, a);
+    hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
   } else {
     hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
   }

@@ -53,8 +53,11 @@ constexpr int GF_LDO = 40;  // staging row stride (floats): 4 rows = 160 = 32 mo
 // tile is a [piece][pixel][channel] bf16 image (pitch 72) in the LDS buffers.
 constexpr int GF_LDB = 72;
 constexpr int GF_PLANE = GF_BM * GF_LDB;  // bf16 elements per piece
-template <bool WT, int SPLIT>
+// S16 (SPLIT == 1, WT): x and ab are bf16-stored (residual-block internals under compute_dtype bf16) and move as 16-byte pieces: the x
+// tile is two 16-byte loads per thread copied straight into the bf16 LDS image, and ab leaves as 8 channels per lane.
+template <bool WT, int SPLIT, bool S16 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a) {
+  static_assert(!S16 || (WT && SPLIT == 1), "bf16 storage: write-through form, bf16 operands");
   constexpr bool BF16 = SPLIT > 0;
   constexpr int NPIECE = SPLIT > 0 ? SPLIT : 1;
   constexpr int A_FLOATS = SPLIT > 1 ? SPLIT * GF_PLANE / 2 : GF_BM * GF_LDA;  // floats per x buffer (SPLIT <= 1: the fp32 tile covers both)
@@ -67,8 +70,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
   const int M = a.M;
 
   // x tile: thread -> rows (t + 256 u) / 16, four channels; rows past M read row 0 and are masked in the epilogue
-  f32x4 av[4];
+  f32x4 av[S16 ? 1 : 4];
+  bf16x8 av8[S16 ? 2 : 1];
   auto load_a = [&](int tile) {
+    if (S16) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = t + 256 * u, r = idx >> 3, k = (idx & 7) * 8;
+        const int m = tile * GF_BM + r;
+        av8[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)(m < M ? m : 0) * 64 + k);
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
@@ -77,6 +90,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
     }
   };
   auto store_a = [&](float* dst) {
+    if (S16) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = t + 256 * u, r = idx >> 3, k = (idx & 7) * 8;
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(dst) + r * GF_LDB + k) = av8[u];
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = t + 256 * u, r = idx >> 4, k = (idx & 15) * 4;
@@ -206,6 +227,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
           os[(wrow + (r & 3) + 8 * (r >> 2)) * GF_LDO + li] = v;
         }
         __builtin_amdgcn_wave_barrier();
+        if (S16 && pass < 2) {  // ab as bf16: 8 channels per lane, rows (lane >> 2) + 16 k of the wave's 32
+          const int r16 = lane >> 2, c8 = (lane & 3) * 8;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int row = r16 + 16 * k, m = tile * GF_BM + wm * 32 + row;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(os + row * GF_LDO + c8), v1 = *reinterpret_cast<const f32x4*>(os + row * GF_LDO + c8 + 4);
+            if (m < M) {
+              const bf16x8 o = to_bf16x8(v0, v1);
+              asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
+                           : : "v"(reinterpret_cast<__bf16*>(a.y) + (size_t)m * 128 + pass * 64 + wn * 32 + c8), "v"(o) : "memory");
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           f32x4 v = *reinterpret_cast<const f32x4*>(os + (rr + 8 * k) * GF_LDO + c4);
@@ -324,7 +360,8 @@ int conv1x1_gate_fwd_try(const lvae_conv_desc* d, const float* res, float* out, 
   const dim3 grid(wgs), block(256);
   if ((a.x_bf16 || a.y_bf16) && !(split == 1 && al)) return -1000;  // bf16 storage: bf16-operand form, aligned buffers
   if ((wt || a.x_bf16 || a.y_bf16) && al) {
-    if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1>), grid, block, 0, s, a);
+    if (split == 1 && a.x_bf16 && (a.y_bf16 || a.y == nullptr)) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1, true>), grid, block, 0, s, a);
+    else if (split == 1) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 1>), grid, block, 0, s, a);
     else if (split == 3) hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 3>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv1x1_gate_fwd_kernel<true, 0>), grid, block, 0, s, a);
   } else {

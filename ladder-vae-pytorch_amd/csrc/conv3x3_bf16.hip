@@ -42,8 +42,14 @@ constexpr int BF_LDK = 72;   // bf16 elements per LDS row (64 channels + 8 pad =
 // PRE (SPLIT == 1 only): the wave's whole B slice is fetched up front (144 registers, two workgroups per CU) — for layers whose grid is a
 // single round of workgroups, where the per-tile latency chain is the launch time; larger grids keep the three-deep ring (87 registers,
 // five workgroups per CU hide the fragment latency by occupancy instead).
-template <int SPLIT, int MI, bool PRE = false>
+// XB / YB (SPLIT == 1, bf16 storage of the tensors inside a residual block): x / y are bfloat16 and move as 16-byte pieces - a thread
+// stages 8 channels of a pixel (one 16-byte load, one ds_write_b128) and the epilogue stores 8 channels per lane (one 16-byte
+// write-through store) - so a bf16 tensor costs half the memory instructions of an fp32 one, not the same number at half the width
+// (8-byte accesses measured SLOWER than fp32 storage: 19.6 vs 17.9 us at 256x16x16). Mixed cases the training step does not produce
+// (bf16 in / fp32 out) take the generic path with the descriptor's run-time dtype flags.
+template <int SPLIT, int MI, bool PRE = false, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
+  static_assert(SPLIT == 1 || (!XB && !YB), "bf16 storage exists for the bf16-operand form only");
   constexpr int BM = 64 * MI, LDK = BF_LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                    // [SPLIT][halo_px][LDK]
@@ -89,8 +95,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
     load_b(1, bq[1]);
   }
 
+  // ---- halo patch, bf16-stored x: every (pixel, 8 channels) once: one 16-byte load, transform in fp32, one 16-byte LDS store
+  if (XB) {
+    const int per_img = a.halo_h * a.halo_w;
+    const int total = a.halo_px * 8;
+    const int c8 = (t & 7) * 8;
+    const bool c_ok = c8 < Cin;   // Cin % 8 == 0 (launcher)
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    if (d.in_scale && c_ok) {
+      sc0 = *reinterpret_cast<const f32x4*>(d.in_scale + c8);
+      sc1 = *reinterpret_cast<const f32x4*>(d.in_scale + c8 + 4);
+      sh0 = *reinterpret_cast<const f32x4*>(d.in_shift + c8);
+      sh1 = *reinterpret_cast<const f32x4*>(d.in_shift + c8 + 4);
+    }
+    const __bf16* xb = reinterpret_cast<const __bf16*>(d.x);
+    const int px0 = t >> 3;
+    for (int base = 0; base < total; base += 256 * 8) {
+      bf16x8 v[8];
+      unsigned okm = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + t + 256 * u;
+        const int px = (base >> 3) + px0 + u * 32;
+        const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+        const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+        const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+        const bool ok = (idx < total) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & c_ok;
+        const unsigned off = ok ? (unsigned)(((n * d.H + ih) * d.W + iw) * Cin + c8) : 0u;
+        v[u] = *reinterpret_cast<const bf16x8*>(xb + off);
+        okm |= ok ? (1u << u) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + t + 256 * u;
+        if (idx < total) {
+          bf16x8 w = v[u];
+          if (d.in_scale) {
+            f32x4 lo = {(float)w[0], (float)w[1], (float)w[2], (float)w[3]}, hi = {(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+            lo = act_fwd4(lo * sc0 + sh0, d.in_act);
+            hi = act_fwd4(hi * sc1 + sh1, d.in_act);
+            w = to_bf16x8(lo, hi);
+          }
+          if (!((okm >> u) & 1u)) w = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          const int px = (base >> 3) + px0 + u * 32;
+          *reinterpret_cast<bf16x8*>(As + px * LDK + c8) = w;
+        }
+      }
+    }
+  }
   // ---- halo patch: every (pixel, 4 channels) once; transform fused, split into planes, zeros outside the image / batch
-  if (!(a.debug & 1)) {
+  if (!XB && !(a.debug & 1)) {
     const int per_img = a.halo_h * a.halo_w;
     const int total = a.halo_px * 16;
     const int c4 = (t & 15) * 4;
@@ -204,6 +258,95 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
     for (int r = 0; r < 16; ++r)
       Os[(wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc[mi][r];
   __syncthreads();
+  if (YB) {
+    // ---- bf16-stored y: 8 channels per lane, one 16-byte write-through store per pixel; statistics from the fp32 values
+    const int c8 = (t & 7) * 8, col = co0 + c8;   // Cout % 8 == 0 (launcher)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 st1[2] = {z4, z4}, st2[2] = {z4, z4}, piv[2] = {z4, z4}, bsh[2] = {z4, z4}, bmu[2] = {z4, z4}, brs[2] = {z4, z4}, bias[2] = {z4, z4};
+    const bool bwd = d.stats_mode == LVAE_STATS_BN_BWD;
+    if (col < d.Cout) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (d.stats_out) piv[h] = *reinterpret_cast<const f32x4*>(d.stats_pivot + col + 4 * h);
+        if (d.stats_out && bwd) {
+          bsh[h] = *reinterpret_cast<const f32x4*>(d.stats_pivot + d.Cout + col + 4 * h);
+          bmu[h] = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col + 4 * h);
+          brs[h] = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col + 4 * h);
+        }
+        if (d.bias) bias[h] = *reinterpret_cast<const f32x4*>(d.bias + col + 4 * h);
+      }
+      const int p0 = t >> 3;
+      __bf16* yb16 = reinterpret_cast<__bf16*>(d.y);
+      const size_t ybase = ((size_t)(n0 * d.H + oh0) * d.W) * d.Cout + col;
+      const bool sxbf = d.stats_x_dtype == LVAE_DT_BF16;
+      const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
+#pragma unroll
+      for (int q = 0; q < BM / 32; ++q) {
+        const int p = p0 + 32 * q;
+        if (p < nvalid) {
+          f32x4 v[2];
+          v[0] = *reinterpret_cast<const f32x4*>(Os + p * LDO + c8) + bias[0];
+          v[1] = *reinterpret_cast<const f32x4*>(Os + p * LDO + c8 + 4) + bias[1];
+          if (d.out_scale) {
+            const int n = n0 + fastdiv(p, a.m_thw);
+            v[0] = v[0] * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
+            v[1] = v[1] * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col + 4);
+          }
+          v[0] = act_fwd4(v[0], d.out_act);
+          v[1] = act_fwd4(v[1], d.out_act);
+          const bf16x8 o = to_bf16x8(v[0], v[1]);
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(yb16 + ybase + (size_t)p * d.Cout), "v"(o) : "memory");
+          if (bwd) {
+            if (d.stats_out) {
+              const size_t xo = (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col;
+              f32x4 xv[2];
+              if (sxbf) {
+                const bf16x8 xq = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.stats_x) + xo);
+                xv[0] = f32x4{(float)xq[0], (float)xq[1], (float)xq[2], (float)xq[3]};
+                xv[1] = f32x4{(float)xq[4], (float)xq[5], (float)xq[6], (float)xq[7]};
+              } else {
+                xv[0] = *reinterpret_cast<const f32x4*>(d.stats_x + xo);
+                xv[1] = *reinterpret_cast<const f32x4*>(d.stats_x + xo + 4);
+              }
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float gj = v[h][j] * act_grad(xv[h][j] * piv[h][j] + bsh[h][j], d.stats_act);
+                  st1[h][j] += gj;
+                  st2[h][j] += gj * (xv[h][j] - bmu[h][j]) * brs[h][j];
+                }
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 dl = v[h] - piv[h];
+              st1[h] += dl;
+              st2[h] += dl * dl;
+            }
+          }
+        }
+      }
+    }
+    if (d.stats_out) {  // 32 pixel groups x 64 channels -> one row of partials per pixel tile (fixed order)
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<f32x4*>(red + (t >> 3) * 64 + c8 + 4 * h) = st1[h];
+        *reinterpret_cast<f32x4*>(red + 2048 + (t >> 3) * 64 + c8 + 4 * h) = st2[h];
+      }
+      __syncthreads();
+      if (t < 128) {
+        const int c = t & 63, which = t >> 6;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v += red[which * 2048 + r * 64 + c];
+        if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
+      }
+    }
+    return;
+  }
   const int c4 = (t & 15) * 4, col = co0 + c4;
   f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1, piv = st1;
   if (d.stats_out && col < d.Cout) piv = *reinterpret_cast<const f32x4*>(d.stats_pivot + col);
@@ -293,8 +436,12 @@ struct BfWgArgs {
 // accumulated (conv3x3_bf16_kernel's fp32-equivalent form). Unlike the forward kernel this one is bound by its slab traffic, not by
 // MFMAs (40 per wave and tile); the six-fold matrix work of SPLIT = 3 was hoped to hide under the memory time but does not (bfwg_form
 // below has the measurement), so SPLIT = 3 is an opt-in form that the parity tests keep exercised.
-template <int MI, int SPLIT>  // tile = 64 * MI pixels
+// XB / DB: x / dy are bf16-stored (residual-block internals under compute_dtype bf16) and are staged as 16-byte pieces: a thread takes 8
+// channels of a pixel (half the memory instructions of the fp32 form; see conv3x3_bf16_kernel). Without them the descriptor's run-time
+// dtype flags are honoured with 4-channel accesses.
+template <int MI, int SPLIT, bool XB = false, bool DB = false>  // tile = 64 * MI pixels
 __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
+  static_assert(SPLIT == 1 || (!XB && !DB), "bf16 storage exists for the bf16-operand form only");
   constexpr int BM = 64 * MI, LDK = BF_LDK, KS = BM / 16;   // k-steps of 16 pixels per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Xs = reinterpret_cast<__bf16*>(smem_raw);          // [SPLIT][halo_px][LDK]
@@ -323,9 +470,20 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   const int drow0 = 8 * (G >> 1) + (i16 >> 2);
 
   // ---- staging maps: thread -> (pixel, 4 channels); raw operands of the next tile live in registers during the MFMAs
-  constexpr int XV = 7;        // float4 of the x patch per thread (halo_px <= 224 checked on the host)
-  constexpr int DV = BM / 32;  // float4 of the dy tile per thread
+  constexpr int XV = XB ? 1 : 7;        // float4 of the x patch per thread (halo_px <= 224 checked on the host)
+  constexpr int DV = DB ? 1 : BM / 32;  // float4 of the dy tile per thread
+  constexpr int XV8 = XB ? 4 : 1;       // 8-channel pieces of a bf16-stored x patch per thread (64 pixels per pass)
+  constexpr int DV8 = DB ? BM / 64 : 1; // ... of a bf16-stored dy tile
   const int c4 = (t & 15) * 4, px0 = t >> 4;
+  const int c8 = (t & 7) * 8, px8 = t >> 3;
+  bf16x8 xr8[XV8], dr8[DV8];
+  f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, sh1 = {0.f, 0.f, 0.f, 0.f}, sc0 = sc1, sh0 = sh1;   // 8-channel mapping: scale / shift of c8 .. c8 + 7
+  if (XB && a.d.in_scale && c8 < a.Cin) {
+    sc0 = *reinterpret_cast<const f32x4*>(a.d.in_scale + c8);
+    sc1 = *reinterpret_cast<const f32x4*>(a.d.in_scale + c8 + 4);
+    sh0 = *reinterpret_cast<const f32x4*>(a.d.in_shift + c8);
+    sh1 = *reinterpret_cast<const f32x4*>(a.d.in_shift + c8 + 4);
+  }
   const bool cx_ok = c4 < Cin, cd_ok = co0 + c4 < d.Cout;
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
   if (d.in_scale && cx_ok) {
@@ -340,6 +498,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
     const int ig = fastdiv(tile, a.m_tiles_h), th_idx = tile - ig * a.tiles_h;
     const int n0 = ig * a.NI, oh0 = th_idx * a.TH;
     xok = 0;
+    if (XB) {
+#pragma unroll
+      for (int u = 0; u < XV8; ++u) {
+        const int px = px8 + 64 * u;
+        const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+        const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+        const int n = n0 + img, ih = oh0 + hy - 1, iw = hx - 1;
+        const bool ok = (px < a.halo_px) & (n < d.N) & ((unsigned)ih < (unsigned)d.H) & ((unsigned)iw < (unsigned)d.W) & (c8 < Cin);
+        const size_t off = ok ? ((size_t)(n * d.H + ih) * d.W + iw) * Cin + c8 : 0;
+        xr8[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.x) + off);
+        xok |= ok ? (1u << u) : 0u;
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < XV; ++u) {
       const int px = px0 + 32 * u;
@@ -353,6 +524,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
     }
     dok = 0;
     const int tile_px = a.NI * a.TH * a.TW;
+    if (DB) {
+#pragma unroll
+      for (int u = 0; u < DV8; ++u) {
+        const int p = px8 + 64 * u;
+        const int img = fastdiv(p, a.m_thw);
+        const bool ok = (p < tile_px) & (n0 + img < d.N) & (co0 + c8 < d.Cout);
+        const size_t off = ok ? ((size_t)(n0 * d.H + oh0) * d.W + p) * d.Cout + co0 + c8 : 0;
+        dr8[u] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.dy) + off);
+        dok |= ok ? (1u << u) : 0u;
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < DV; ++u) {
       const int p = px0 + 32 * u;
@@ -369,12 +551,30 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   for (int j = 0; j < 5; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  f32x4 bsum = zero4;
+  f32x4 bsum = zero4, bsum8 = zero4;   // bias-gradient partials (bsum8: channels c8 + 4 .. c8 + 7 of the 8-channel mapping)
 
   int tile = blockIdx.x;
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += gridDim.x) {
     // ---- registers -> LDS images (transform + round to bf16); rows that do not exist are zero
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (XB) {
+#pragma unroll
+      for (int u = 0; u < XV8; ++u) {
+        const int px = px8 + 64 * u;
+        if (px < a.halo_px) {
+          bf16x8 w = xr8[u];
+          if (d.in_scale) {
+            f32x4 lo = {(float)w[0], (float)w[1], (float)w[2], (float)w[3]}, hi = {(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+            lo = act_fwd4(lo * sc0 + sh0, d.in_act);
+            hi = act_fwd4(hi * sc1 + sh1, d.in_act);
+            w = to_bf16x8(lo, hi);
+          }
+          if (!((xok >> u) & 1u)) w = zero8;
+          *reinterpret_cast<bf16x8*>(Xs + px * LDK + c8) = w;
+        }
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < XV; ++u) {
       const int px = px0 + 32 * u;
@@ -390,6 +590,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
         for (int q = 0; q < SPLIT; ++q) *reinterpret_cast<bf16x4*>(Xs + q * x_plane + px * LDK + c4) = pl[q];
       }
     }
+    if (DB) {
+#pragma unroll
+      for (int u = 0; u < DV8; ++u) {
+        const int p = px8 + 64 * u;
+        const bf16x8 w = ((dok >> u) & 1u) ? dr8[u] : zero8;
+        bsum += f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+        bsum8 += f32x4{(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+        *reinterpret_cast<bf16x8*>(Ds + p * LDK + c8) = w;
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < DV; ++u) {
       const int p = px0 + 32 * u;
@@ -448,13 +658,19 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
     }
   }
   if (a.slab_b) {
-    float* red = reinterpret_cast<float*>(smem_raw);   // [32 pixel groups][64]
-    *reinterpret_cast<f32x4*>(red + px0 * 64 + c4) = bsum;
+    float* red = reinterpret_cast<float*>(smem_raw);   // [32 | 64 pixel groups][64]
+    constexpr int NG = DB ? 64 : 32;
+    if (DB) {
+      *reinterpret_cast<f32x4*>(red + px8 * 64 + c8) = bsum;
+      *reinterpret_cast<f32x4*>(red + px8 * 64 + c8 + 4) = bsum8;
+    } else {
+      *reinterpret_cast<f32x4*>(red + px0 * 64 + c4) = bsum;
+    }
     __syncthreads();
     if (t < 64) {
       float v = 0.f;
 #pragma unroll
-      for (int g = 0; g < 32; ++g) v += red[g * 64 + t];
+      for (int g = 0; g < NG; ++g) v += red[g * 64 + t];
       if (co0 + t < d.Cout) a.slab_b[(size_t)blockIdx.x * d.Cout + co0 + t] = v;
     }
   }
@@ -606,9 +822,9 @@ int conv3x3_bf16_stats_rows(const lvae_conv_desc* d, int split) {
   return ((d->N + a.NI - 1) / a.NI) * a.tiles_h;
 }
 
-template <int SPLIT, int MI, bool PRE = false>
+template <int SPLIT, int MI, bool PRE = false, bool XB = false, bool YB = false>
 static int launch_bf(BfArgs a, hipStream_t s) {
-  auto kern = conv3x3_bf16_kernel<SPLIT, MI, PRE>;
+  auto kern = conv3x3_bf16_kernel<SPLIT, MI, PRE, XB, YB>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -646,6 +862,15 @@ int conv3x3_bf16_try(const lvae_conv_desc* d, int split, hipStream_t s) {
   if (split == 1) {
     const int64_t wgs = (int64_t)((d->N + a.NI - 1) / a.NI) * a.tiles_h * a.ntn;
     const bool pre = wgs <= 512;  // one round of two workgroups per CU (measured: 16x16 19.9 -> 18.0 us, 8x8 13.8 -> 9.8; 32x32 53 -> 65 with it)
+    const bool xb = d->x_dtype == LVAE_DT_BF16, yb = d->y_dtype == LVAE_DT_BF16;
+    if (yb && d->C1 % 8 == 0 && d->Cout % 8 == 0) {   // bf16-stored residual-block tensors: the 16-byte forms
+      if (xb) {
+        if (a.bm == 128) return pre ? launch_bf<1, 2, true, true, true>(a, s) : launch_bf<1, 2, false, true, true>(a, s);
+        return pre ? launch_bf<1, 1, true, true, true>(a, s) : launch_bf<1, 1, false, true, true>(a, s);
+      }
+      if (a.bm == 128) return pre ? launch_bf<1, 2, true, false, true>(a, s) : launch_bf<1, 2, false, false, true>(a, s);
+      return pre ? launch_bf<1, 1, true, false, true>(a, s) : launch_bf<1, 1, false, false, true>(a, s);
+    }
     if (a.bm == 128) return pre ? launch_bf<1, 2, true>(a, s) : launch_bf<1, 2>(a, s);
     return pre ? launch_bf<1, 1, true>(a, s) : launch_bf<1, 1>(a, s);
   }
@@ -719,7 +944,16 @@ int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, 
   size_t lds = (size_t)a.split * (a.halo_px + a.bm) * BF_LDK * 2;
   if (lds < 32 * 64 * 4) lds = 32 * 64 * 4;
   const dim3 grid(nwg, (d->Cout + 63) / 64);
-  if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), lds, s, a);
+  if (lds < 64 * 64 * 4) lds = 64 * 64 * 4;   // bias-gradient reduction of the 8-channel mapping
+  const bool xb = d->x_dtype == LVAE_DT_BF16, dyb = d->y_dtype == LVAE_DT_BF16;
+  const bool c8ok = d->C1 % 8 == 0 && d->Cout % 8 == 0;
+  if (dyb && c8ok && xb) {
+    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1, true, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1, true, true>), grid, dim3(512), lds, s, a);
+  } else if (dyb && c8ok) {
+    if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1, false, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1, false, true>), grid, dim3(512), lds, s, a);
+  } else if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1>), grid, dim3(512), lds, s, a);
   else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<1, 1>), grid, dim3(512), lds, s, a);
   LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16");
   wgrad_reduce_launch(a.slab_w, a.slab_b, nwg, 9, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
