@@ -426,6 +426,8 @@ int lvae_l2norm_f32(const float* x, int64_t n, float* out, void* workspace, size
 int lvae_rng_fill_f32(float* out, int64_t n, int32_t kind, float lo, float hi, uint64_t seed, const uint64_t* offset,
                       uint64_t stream_id, void* stream);
 int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream);
+/* out[0:n] = value (16-byte aligned out). replaces: optimizer.zero_grad() of boilr's training loop on the flat gradient arena. */
+int lvae_fill_f32(float* out, int64_t n, float value, void* stream);
 
 #ifdef __cplusplus
 }

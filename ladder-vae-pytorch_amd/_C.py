@@ -114,6 +114,7 @@ SIGNATURES = {
     'lvae_l2norm_f32': (C.c_int, [_P, _L, _P, _P, _Z, _P]),
     'lvae_rng_fill_f32': (C.c_int, [_P, _L, _I, _F, _F, _U, _P, _U, _P]),
     'lvae_counter_advance': (C.c_int, [_P, _U, _P]),
+    'lvae_fill_f32': (C.c_int, [_P, _L, _F, _P]),
 }
 
 _lib = None

@@ -88,7 +88,11 @@ class ParamArena:
             off += sz
 
     def zero_grad(self):
-        self.grads.zero_()
+        from . import kernels as K
+        if self.grads.is_cuda:
+            K.fill(self.grads, 0.0)     # our own kernel: no torch fill inside the (captured) step
+        else:
+            self.grads.zero_()           # CPU arenas exist only in the host-logic tests
 
     def owns(self, p):
         a = self.params

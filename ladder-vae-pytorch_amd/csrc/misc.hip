@@ -440,6 +440,21 @@ extern "C" int lvae_rng_fill_f32(float* out, int64_t n, int32_t kind, float lo, 
   return 0;
 }
 
+// out[0:n] = value: the gradient arena's zero_grad (16-byte stores; n * 4 bytes need not be a multiple of 16)
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ out, int64_t n, float value) {
+  const int64_t n4 = n >> 2;
+  const f32x4 v = {value, value, value, value};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<f32x4*>(out)[i] = v;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = value;
+}
+
+extern "C" int lvae_fill_f32(float* out, int64_t n, float value, void* stream) {
+  LVAE_REQUIRE(out != nullptr && n > 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, LVAE_EINVAL, "lvae_fill_f32: null / misaligned buffer");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n >> 2, 256 * 4)), dim3(256), 0, (hipStream_t)stream, out, n, value);
+  LVAE_LAUNCH_CHECK("fill");
+  return 0;
+}
+
 extern "C" int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream) {
   LVAE_REQUIRE(counter != nullptr, LVAE_EINVAL, "lvae_counter_advance: null counter");
   hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, by);

@@ -571,6 +571,12 @@ def add(a, b):
     return out
 
 
+def fill(t, value=0.0):
+    """t[...] = value with our own kernel (t contiguous float32, 16-byte aligned): the gradient arena's zero_grad."""
+    call('lvae_fill_f32', ptr(t), t.numel(), float(value), stream_ptr())
+    return t
+
+
 def fill_zero(t):
     """zero a (small) tensor with our own kernel: out = 0 * out is not safe for NaN garbage, so scale_rows_add of a cached zero"""
     z = _zeros_like_cached(t)
