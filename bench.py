@@ -41,6 +41,7 @@ PEAK_MFMA_BF16 = 2500.0        # TFLOP/s dense, MI355X_MICROARCH.md
 ROCPROF_SUMMARIES = ('profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
 PMC_SUMMARIES = ('profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
 PMC_SUMMARIES_BF16 = ('profiles/r03_pmc/hbm_traffic_bf16.json',)
+ROCPROF_SUMMARIES_BF16 = ('profiles/r03_bf16_kernel_by_grid.txt', 'profiles/r02_bf16_kernel_by_grid.txt')
 
 
 def first_existing(paths):
@@ -117,16 +118,16 @@ def conv_roofline(model, x):
     return dom, fam_f, fam_ms, len(rec), variants.get(dom[0], 0)
 
 
-def pmc_traffic(dom_key, is_wino):
+def pmc_traffic(dom_key, kname, wgs, paths=PMC_SUMMARIES):
     """HBM bytes per launch of the dominant kernel from a committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 half-count correction). Returns (bytes | None, source)."""
-    for rel in PMC_SUMMARIES:
+    for rel in paths:
         path = os.path.join(ROOT, rel)
         if dom_key != 'conv 3x3 s1 64->64 @256x16x16' or not os.path.exists(path):
             continue
         meta = json.load(open(path))
-        prefix = 'conv3x3_wino_kernel' if is_wino else 'conv3x3_halo_kernel'
-        vals = [v['hbm_bytes_per_launch'] for k, v in meta['kernels'].items() if k.startswith(prefix) and k.endswith('@512 workgroups')]
+        prefix = kname.split('<')[0]
+        vals = [v['hbm_bytes_per_launch'] for k, v in meta['kernels'].items() if k.startswith(prefix) and k.endswith('@%d workgroups' % wgs)]
         if vals:
             return sum(vals) / len(vals), '%s (%s)' % (rel, meta.get('scope', 'single-layer micro-benchmark tools/conv_bench.py, not the whole step'))
     return None, None
@@ -141,15 +142,19 @@ def pmc_step(paths=PMC_SUMMARIES):
     return (st['hbm_bytes_per_step'], rel) if st else (None, None)
 
 
-def rocprof_avg_us(kernel_prefix, wgs):
-    """Average duration of `kernel_prefix` at `wgs` workgroups from the committed rocprofv3 --kernel-trace summary."""
-    rel = first_existing(ROCPROF_SUMMARIES)
+def rocprof_avg_us(kernel_prefix, wgs, paths=None):
+    """Average duration of `kernel_prefix` at `wgs` workgroups from the committed rocprofv3 --kernel-trace summary (call-weighted over the
+    template instances that match)."""
+    rel = first_existing(paths or ROCPROF_SUMMARIES)
     if rel is None:
         return None
+    calls = tot = 0.0
     for line in open(os.path.join(ROOT, rel)):
         if line.startswith(kernel_prefix) and ('wgs=%6d' % wgs) in line and 'avg=' in line:
-            return float(line.split('avg=')[1].split()[0])
-    return None
+            n = float(line.split('calls=')[1].split()[0])
+            calls += n
+            tot += n * float(line.split('avg=')[1].split()[0])
+    return tot / calls if calls else None
 
 
 def oracle_images_per_s(cfg, batch, warm, steps):
@@ -252,7 +257,7 @@ def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
     V = K._C
     if kind == V.VARIANT_WINO_SIX:   # Winograd F(2x2,3x3): 16/36 of the direct multiplies, each as six bf16-piece products on the bf16 MFMA
         issued, peak, unit = f_alg * 16.0 / 36.0 * 6.0, PEAK_MFMA_BF16, 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), six exact bf16-piece products per fp32 product'
-        kname = 'conv3x3_wino_kernel<64, 2, 1, true>'
+        kname = 'conv3x3_wino2_kernel'
     elif kind == V.VARIANT_WINO_F32:
         issued, peak, unit, kname = f_alg * 16.0 / 36.0, PEAK_MFMA_F32, 'fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'conv3x3_wino_kernel<64, 2, 1, false>'
     elif kind == V.VARIANT_BF16_DIRECT:
@@ -263,7 +268,9 @@ def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
         issued, peak, unit, kname = f_alg, PEAK_MFMA_F32, 'fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'conv3x3_pos_kernel / conv3x3_halo_kernel / conv1x1_kernel / conv_igemm_kernel'
     ach = issued / t / 1e12
     hbm = b_alg / t / 1e9
-    traffic, traffic_src = pmc_traffic(dkey, kind in (V.VARIANT_WINO_SIX, V.VARIANT_WINO_F32)) if dtype == 'f32' else (None, None)
+    # workgroups of the dominant shape (256x16x16): 256-pixel tiles for the 8-wave Winograd kernel, 128-pixel tiles otherwise
+    wgs = 256 if kind == V.VARIANT_WINO_SIX else 512
+    traffic, traffic_src = pmc_traffic(dkey, kname, wgs, PMC_SUMMARIES if dtype == 'f32' else PMC_SUMMARIES_BF16)
     rec = {
         'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
         'traffic': traffic, 'traffic_source': traffic_src,
@@ -273,7 +280,8 @@ def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
         'effective_frac_of_fp32_mfma_peak': f_alg / t / 1e12 / PEAK_MFMA_F32,
         'algorithmic_bytes_per_launch': b_alg, 'hbm_gb_per_s': hbm, 'hbm_frac_of_peak': hbm / PEAK_HBM,
         'launches_per_step': dn, 'avg_launch_us': t * 1e6,
-        'avg_launch_us_rocprof': rocprof_avg_us(kname, 512), 'rocprof_summary': first_existing(ROCPROF_SUMMARIES),
+        'avg_launch_us_rocprof': rocprof_avg_us(kname.split('<')[0], wgs, ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16),
+        'rocprof_summary': first_existing(ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16),
         'note': 'frac = FLOPs the matrix unit ISSUES per launch / avg launch time / that unit\'s dense peak. effective_tflops counts the '
                 'ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*9) the launch replaces. The kernel is bound by neither pipe peak: '
                 'see the SQ counters named in DESIGN.md §5 (vector instructions per MFMA, parked waves).',

@@ -1,5 +1,6 @@
 """profiles/<round>_pmc/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over an EAGER training step
-(tools/r02_pmc_step.sh). usage: python tools/pmc_step_json.py <FETCH csv> <WRITE csv> <n steps in the run> <out json>"""
+(tools/r03_pmc_step.sh). usage: python tools/pmc_step_json.py <FETCH csv> <WRITE csv> <n steps in the run> <out json> [bytes per image of the
+algorithmic convolution traffic: 115.93e6 fp32 (default), 57.96e6 for bf16 storage]"""
 import collections
 import csv
 import json
@@ -26,8 +27,9 @@ def collect(path, counter):
 ft, fc = collect(sys.argv[1], 'FETCH_SIZE')
 wt, wc = collect(sys.argv[2], 'WRITE_SIZE')
 nsteps = float(sys.argv[3])
+b_img = float(sys.argv[5]) if len(sys.argv) > 5 else 115.93e6
 out = {'scope': 'whole training step, eager launches (bench.py --no-graph), %d steps in the run' % nsteps,
-       'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/r02_pmc_step.sh) on MI355X; hbm_bytes = '
+       'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/r03_pmc_step.sh) on MI355X; hbm_bytes = '
                  '(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half the bytes of a wide coalesced read: '
                  'MI355X_MICROARCH.md, HBM section; Infinity-Cache hits are included in the counters)',
        'kernels': {}}
@@ -40,8 +42,8 @@ for k in ft:
     step_f += ft[k] / nsteps
     step_w += wt[k] / nsteps
 out['step'] = {'FETCH_SIZE_KB': step_f, 'WRITE_SIZE_KB': step_w, 'hbm_bytes_per_step': (2 * step_f + step_w) * 1024,
-               'algorithmic_conv_bytes_per_step': 115.93e6 * 256}
+               'algorithmic_conv_bytes_per_step': b_img * 256}
 json.dump(out, open(sys.argv[4], 'w'), indent=1)
-print('step: %.2f GB (2*FETCH + WRITE); algorithmic conv traffic %.2f GB' % (out['step']['hbm_bytes_per_step'] / 1e9, 115.93e6 * 256 / 1e9))
+print('step: %.2f GB (2*FETCH + WRITE); algorithmic conv traffic %.2f GB' % (out['step']['hbm_bytes_per_step'] / 1e9, b_img * 256 / 1e9))
 for k, v in sorted(out['kernels'].items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_per_step'])[:14]:
     print('%-60s %8.1f MB/launch x %6.1f /step' % (k, v['hbm_bytes_per_launch'] / 1e6, v['launches_per_step']))
