@@ -97,6 +97,7 @@ def conv_roofline(model, x):
         rec.append((key, flops, nbytes, e0, e1))
 
     K.call = timed_call
+    tracker, model.grad_tracker = getattr(model, 'grad_tracker', None), None   # this instrumented step is local to rank 0: no gradient exchange
     try:
         model.zero_grad()
         K.prepared.prepare_all()  # as in the training step: the per-launch records below are the convolution kernels alone
@@ -105,6 +106,7 @@ def conv_roofline(model, x):
         torch.cuda.synchronize()
     finally:
         K.call = orig
+        model.grad_tracker = tracker
     groups = {}
     for key, f, nb, e0, e1 in rec:
         g = groups.setdefault(key, [0, 0.0, 0.0, 0.0])

@@ -40,13 +40,10 @@ __global__ __launch_bounds__(256) void bernoulli_fwd_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Discretized mixture of logistics (lib/likelihoods.py:291-382), NMIX = 10
-// parameter layout per pixel: [0,10) logits; colour c block at 10+30c: [+0,10) means, [+10,20) log-scales, [+20,30) coeffs
+// Discretized mixture of logistics (lib/likelihoods.py:291-382) with NMIX components (the reference's default and only use: 10;
+// lib/likelihoods.py:183-202 takes any count, so the kernels are instantiated for 1-6, 8, 10, 12, 16 and 20)
+// parameter layout per pixel: [0,NMIX) logits; colour c block at NMIX+3*NMIX*c: [+0,NMIX) means, [+NMIX,2NMIX) log-scales, [+2NMIX,3NMIX) coeffs
 // ---------------------------------------------------------------------------------------------------------
-constexpr int NMIX = 10;
-constexpr int NP = 10 * NMIX;       // 100
-constexpr int NPS = NP + 1;         // padded LDS row
-constexpr int DM_PIX = 128;         // pixels per workgroup
 
 struct ColourTerm {
   float lp, dmean, dls;
@@ -84,9 +81,11 @@ __device__ __forceinline__ ColourTerm dmol_colour(float x, float mean, float ls_
   return r;
 }
 
+template <int NMIX, int DM_PIX>  // DM_PIX pixels per workgroup: 128 while their parameter rows fit the 64 KB of static LDS, else 64
 __global__ __launch_bounds__(DM_PIX) void dmol_ll_kernel(const float* __restrict__ l, const float* __restrict__ x,
                                                           int64_t npix, float* __restrict__ ll_pix,
                                                           float* __restrict__ dl) {
+  constexpr int NP = 10 * NMIX, NPS = NP + 1;  // parameters per pixel, padded LDS row
   __shared__ float buf[DM_PIX * NPS];
   const int t = threadIdx.x;
   const int64_t p0 = (int64_t)blockIdx.x * DM_PIX;
@@ -173,9 +172,11 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ v
 }
 
 // lib/stochastic.py:141-206 and the rescale/clamp of lib/likelihoods.py:221-225
+template <int NMIX>
 __global__ __launch_bounds__(256) void dmol_sample_kernel(const float* __restrict__ l, const float* __restrict__ u_mix,
                                                            const float* __restrict__ u_log, int64_t npix,
                                                            float* __restrict__ sample) {
+  constexpr int NP = 10 * NMIX;
   for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * 256) {
     const float* row = l + pix * NP;
     int sel = 0;
@@ -310,17 +311,35 @@ extern "C" int lvae_bernoulli_fwd_f32(const float* logits, const float* x, const
 
 extern "C" size_t lvae_dmol_workspace(int32_t N, int32_t HW) { return (size_t)N * HW * sizeof(float); }
 
+// component counts the DMoL kernels are instantiated for
+#define LVAE_DMOL_COUNTS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12) X(16) X(20)
+static bool dmol_supported(int nmix) {
+  switch (nmix) {
+#define X(n) case n:
+    LVAE_DMOL_COUNTS(X)
+#undef X
+    return true;
+    default: return false;
+  }
+}
+
 extern "C" int lvae_dmol_ll_fwd_f32(const float* l, const float* x, int32_t N, int32_t HW, int32_t nmix, float* ll,
                                     float* dll_dl, void* workspace, size_t workspace_bytes, void* stream) {
   LVAE_REQUIRE(l && x && ll && workspace && N > 0 && HW > 0, LVAE_EINVAL, "lvae_dmol_ll_fwd_f32: bad args");
-  LVAE_REQUIRE(nmix == NMIX, LVAE_EINVAL, "lvae_dmol_ll_fwd_f32: only %d mixture components are supported (got %d)", NMIX,
-               nmix);
+  LVAE_REQUIRE(dmol_supported(nmix), LVAE_EINVAL, "lvae_dmol_ll_fwd_f32: %d mixture components: instantiated for 1-6, 8, 10, 12, 16, 20", nmix);
   LVAE_REQUIRE(workspace_bytes >= lvae_dmol_workspace(N, HW), LVAE_EWORKSPACE, "lvae_dmol_ll_fwd_f32: workspace");
   const int64_t npix = (int64_t)N * HW;
   hipStream_t s = (hipStream_t)stream;
   float* ll_pix = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(dmol_ll_kernel, dim3((unsigned)((npix + DM_PIX - 1) / DM_PIX)), dim3(DM_PIX), 0, s, l, x, npix, ll_pix,
-                     dll_dl);
+  switch (nmix) {
+#define X(n)                                                                                                                         \
+  case n: {                                                                                                                          \
+    constexpr int PIX = (128 * (10 * n + 1) * 4 <= 64 * 1024) ? 128 : 64;                                                            \
+    hipLaunchKernelGGL((dmol_ll_kernel<n, PIX>), dim3((unsigned)((npix + PIX - 1) / PIX)), dim3(PIX), 0, s, l, x, npix, ll_pix, dll_dl); \
+  } break;
+    LVAE_DMOL_COUNTS(X)
+#undef X
+  }
   LVAE_LAUNCH_CHECK("dmol_ll");
   hipLaunchKernelGGL(rowsum_kernel, dim3(N), dim3(256), 0, s, ll_pix, (int64_t)HW, ll);
   LVAE_LAUNCH_CHECK("dmol_rowsum");
@@ -330,10 +349,14 @@ extern "C" int lvae_dmol_ll_fwd_f32(const float* l, const float* x, int32_t N, i
 extern "C" int lvae_dmol_sample_f32(const float* l, const float* u_mix, const float* u_log, int32_t N, int32_t HW,
                                     int32_t nmix, float* sample, void* stream) {
   LVAE_REQUIRE(l && u_mix && u_log && sample && N > 0 && HW > 0, LVAE_EINVAL, "lvae_dmol_sample_f32: bad args");
-  LVAE_REQUIRE(nmix == NMIX, LVAE_EINVAL, "lvae_dmol_sample_f32: only %d mixture components are supported", NMIX);
+  LVAE_REQUIRE(dmol_supported(nmix), LVAE_EINVAL, "lvae_dmol_sample_f32: %d mixture components: instantiated for 1-6, 8, 10, 12, 16, 20", nmix);
   const int64_t npix = (int64_t)N * HW;
-  hipLaunchKernelGGL(dmol_sample_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, l, u_mix, u_log,
-                     npix, sample);
+  switch (nmix) {
+#define X(n) \
+  case n: hipLaunchKernelGGL(dmol_sample_kernel<n>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, l, u_mix, u_log, npix, sample); break;
+    LVAE_DMOL_COUNTS(X)
+#undef X
+  }
   LVAE_LAUNCH_CHECK("dmol_sample");
   return 0;
 }

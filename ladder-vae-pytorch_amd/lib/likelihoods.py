@@ -31,18 +31,22 @@ class BernoulliLikelihood(LikelihoodModule):
 
 
 class DiscretizedLogisticMixLikelihood(LikelihoodModule):
-    """10-component mixture (PixelCNN++ form). Mean and mode are None, as in the reference (lib/likelihoods.py:207-218)."""
+    """Mixture of n_components discretized logistics (PixelCNN++ form; the reference's only use is 10). Mean and mode are None, as in
+    the reference (lib/likelihoods.py:207-218)."""
+
+    SUPPORTED = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20)   # counts the kernels are instantiated for (csrc/likelihood.hip)
 
     def __init__(self, ch_in, n_components=10):
         super().__init__()
-        if n_components != 10:
-            raise NotImplementedError("the DMoL kernels are built for 10 mixture components")
+        if n_components not in self.SUPPORTED:
+            raise NotImplementedError("the DMoL kernels are instantiated for %s mixture components, not %r" % (self.SUPPORTED, n_components))
+        self.n_components = n_components
         self.parameter_net = Conv2dParams(ch_in, 10 * n_components, 3, padding=1)
 
     def forward(self, input_, x, noise):
         l = self.parameter_net(input_)
         N, H, W, _ = l.shape
-        u_mix = noise.uniform((N, H, W, 10), 1e-5, 1. - 1e-5, l.device)
+        u_mix = noise.uniform((N, H, W, self.n_components), 1e-5, 1. - 1e-5, l.device)
         u_log = noise.uniform((N, H, W, 3), 1e-5, 1. - 1e-5, l.device)
         with torch.no_grad():
             sample = K.dmol_sample(l.detach(), u_mix, u_log)

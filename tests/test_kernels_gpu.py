@@ -834,3 +834,29 @@ def test_conv3x3_wgrad_bf16_operands(K, case):
         K.set_precision('f32')
     assert rel(dw.cpu() - dw0, w64.grad.float()) < 3e-4     # bf16 rounding boundaries of the GPU's fast-exp ELU vs the CPU's
     assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 1e-5    # the bias gradient sums the unrounded dy
+
+
+@pytest.mark.parametrize('nmix', [1, 5, 10, 16, 20])
+def test_dmol_any_component_count_matches_oracle(K, nmix):
+    """DiscretizedLogisticMixLikelihood(n_components) of lib/likelihoods.py:183-202 takes any count (the reference only ever builds 10):
+    log-likelihood, its gradient and the sampler for the counts the kernels are instantiated for, against the oracle's restatement of
+    lib/likelihoods.py:291-382 and lib/stochastic.py:141-206 (whose 10-component case is pinned by the reference's own vectors)."""
+    from oracle import lvae_ref as R
+    g = torch.Generator().manual_seed(100 + nmix)
+    N, H, W = 3, 8, 8
+    l = torch.randn(N, 10 * nmix, H, W, generator=g)
+    x01 = torch.floor(256 * torch.rand(N, 3, H, W, generator=g)) / 255
+    x01[0, :, 0, 0], x01[0, :, 0, 1] = 0.0, 1.0            # the two edge bins
+    l64 = l.double().requires_grad_(True)
+    ll_ref = R.discretized_mix_logistic_ll((x01 * 2 - 1).double(), l64)
+    ll_ref.sum().backward()
+    ll, dl = K.dmol_ll_fwd(nhwc(l), nhwc(x01), True)
+    torch.testing.assert_close(ll.cpu().double(), ll_ref.detach(), rtol=1e-5, atol=1e-3)
+    assert rel(nchw(dl).double(), l64.grad) < 2e-4
+    tape = R.Tape(gen=torch.Generator().manual_seed(7))
+    s_ref = R.sample_discretized_mix_logistic(l, tape)
+    u_mix, u_log = [torch.as_tensor(e).float().cuda().contiguous() for e in tape.entries]
+    s = K.dmol_sample(nhwc(l), u_mix, u_log)
+    torch.testing.assert_close(nchw(s) * 2 - 1, s_ref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(K._C.LvaeHipError):
+        K.dmol_ll_fwd(nhwc(torch.randn(1, 70, 4, 4)), nhwc(torch.rand(1, 3, 4, 4)), False)      # 7 components: not instantiated
