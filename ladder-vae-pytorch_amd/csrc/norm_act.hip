@@ -731,7 +731,9 @@ extern "C" int lvae_affine_act_bwd_parts_f32(const float* parts, int32_t rows, c
   // measured on the CIFAR-15 step (one box): 128 -> 36.96 ms, 256 -> 37.28, 1024 -> 37.54: beyond 128 rows the redundant per-workgroup sums cost
   // more than the finalize launch they replace
   static const int parts_max_rows = (int)tune("LVAE_APPLY_PARTS_MAX_ROWS", 128);
-  if (rows <= parts_max_rows && vec_ok(C, x, dh, dx, add) && vec_ok(C, parts, drop) && 256 % (C / 4) == 0) {
+  // ... except where few workgroups do the summing: the 8x8 level under LVAE_PREC_BF16 has 256 partial rows (64-pixel tiles) and 256 apply workgroups
+  const bool few_wgs = rows <= 2 * parts_max_rows && M <= 16384;
+  if ((rows <= parts_max_rows || few_wgs) && vec_ok(C, x, dh, dx, add) && vec_ok(C, parts, drop) && 256 % (C / 4) == 0) {
     const RowMap rm = row_map(C, 4);
     const int grid = grid_for(M, rm.rpp * 4);
     hipLaunchKernelGGL(affine_bwd_apply_parts_kernel, dim3(grid), dim3(256), 0, s, parts, rows, dh, x, (int)M, C, rm.cols, rm.rpp, scale,
