@@ -86,7 +86,9 @@ def conv_roofline(model, x):
         flops = 2.0 * d.N * d.OH * d.OW * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
         if d.gather == 1 and d.stride > 1:
             flops /= d.stride * d.stride  # taps that hit no input pixel are not algorithmic work
-        nbytes = 4.0 * (d.N * d.H * d.W * (d.C1 + d.C2) + d.N * d.OH * d.OW * d.Cout + d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
+        # algorithmic bytes of the launch: input + output tensors in their STORAGE type (bf16-stored residual-block tensors: 2 B), fp32 weights
+        nbytes = ((2.0 if d.x_dtype else 4.0) * d.N * d.H * d.W * (d.C1 + d.C2) + (2.0 if d.y_dtype else 4.0) * d.N * d.OH * d.OW * d.Cout +
+                  4.0 * d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
         key = 'conv %dx%d s%d %d->%d @%dx%dx%d' % (d.KH, d.KW, d.stride, d.C1 + d.C2, d.Cout, d.N, d.OH, d.OW)
         if name == 'lvae_conv2d_f32':
             variants[key] = K._C.load().lvae_conv2d_variant(args[0])
