@@ -57,4 +57,31 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&out)[SPLIT]) {
   }
 }
 
+// Exact three-piece split of eight fp32 values straight into the three bf16x8 MFMA operand pieces, written pairwise so that hipcc
+// emits ONE v_cvt_pk_bf16_f32 per two values and stage (left to itself it converts many values one at a time and converts again to
+// pack: 6.5-7.5 vector instructions per value in the emitted code of the Winograd kernels; this form is 5.5): per pair and stage
+// cvt_pk, two widenings (shift / mask of the packed word), two subtractions; the packed words ARE the operand pieces.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8_3(const f32x4 lo, const f32x4 hi, bf16x8 (&af)[3]) {
+  u32x4 w[3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float a = p < 2 ? lo[2 * p] : hi[2 * p - 4], b = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bf16x2 h = __builtin_convertvector(f32x2v{a, b}, bf16x2);
+      const unsigned bits = __builtin_bit_cast(unsigned, h);
+      w[q][p] = bits;
+      if (q < 2) {
+        a -= __builtin_bit_cast(float, bits << 16);          // exact: the remainder of a round-to-nearest to 8 bits has <= 16 significant bits
+        b -= __builtin_bit_cast(float, bits & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) af[q] = __builtin_bit_cast(bf16x8, w[q]);
+}
+
 }  // namespace lvae

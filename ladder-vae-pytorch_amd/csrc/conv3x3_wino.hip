@@ -547,6 +547,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 #ifndef LVAE_W2_SGB
 #define LVAE_W2_SGB 0
 #endif
+#ifndef LVAE_W2_PAIRSPLIT
+#define LVAE_W2_PAIRSPLIT 1
+#endif
 constexpr int W2_LDS_R = 8 * 2 * 32 * WLDO * 4;  // bytes of the partial-sum exchange of one block
 
 __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
@@ -558,6 +561,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int prow = wave >> 1, jp = wave & 1;  // position row i, column pair: positions 4 i + 2 jp + {0, 1}
   WINO_STAMP(0);
+#ifdef LVAE_WINO_DBG  // compile-time phase-skip mask of the profiling builds (tools/wino_ab.sh); never defined in the product
+  constexpr int dbg = LVAE_WINO_DBG;  // 1: no halo loads, 4: no output stores, 8: U from one hot KB, 16: no epilogue at all, 32: no split (MFMAs on raw bits)
+#else
+  constexpr int dbg = 0;
+#endif
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
@@ -594,7 +602,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
     for (int u = 0; u < SLOTS; ++u) {
       const bool live = hoff[u] != ~0u && 16 * c + hc4 < a.Cin;
       const unsigned off = live ? hoff[u] + 16 * c : 0u;
-      hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
+      if (dbg & 1) hreg[u] = zero4;
+      else hreg[u] = *reinterpret_cast<const f32x4*>(d.x + off);
       hlive = live ? hlive | (1u << u) : hlive & ~(1u << u);
     }
   };
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
     constexpr int BR = LVAE_W2_RING, NIT = 2 * NSLICE;
     bf16x8 bq[BR][NH][3];
     auto load_b = [&](int it, int buf) {  // it = 2 s + jj
-      const __bf16* p = u3 + (size_t)((4 * prow + 2 * jp + (it & 1)) * 4 + (it >> 1)) * NB * 1536;
+      const __bf16* p = u3 + ((dbg & 8) ? (size_t)0 : (size_t)((4 * prow + 2 * jp + (it & 1)) * 4 + (it >> 1)) * NB * 1536);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -692,11 +701,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
           vh[e] = __builtin_fmaf(s2, th[m][2][e], th[m][1][e]);
         }
       }
+      if (dbg & 32) {
+        af[0] = __builtin_bit_cast(bf16x8, vl);
+        af[1] = __builtin_bit_cast(bf16x8, vh);
+        af[2] = __builtin_bit_cast(bf16x8, vl + vh);
+        return;
+      }
+#if LVAE_W2_PAIRSPLIT
+      split8_3(vl, vh, af);
+#else
       bf16x4 pl[3], ph[3];
       split4<3>(vl, pl);
       split4<3>(vh, ph);
 #pragma unroll
       for (int q = 0; q < 3; ++q) af[q] = bf16x8{pl[q][0], pl[q][1], pl[q][2], pl[q][3], ph[q][0], ph[q][1], ph[q][2], ph[q][3]};
+#endif
     };
 #pragma unroll
     for (int s16 = 0; s16 < NSLICE; ++s16) {
@@ -751,6 +770,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
   WINO_STAMP(2);
   __syncthreads();  // every wave is done with the halo patch: LDS becomes the partial sums of one block
   WINO_STAMP(3);
+  if (dbg & 16) {
+    float keep = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) keep += acc[m][j][h][m + j + h];
+    if (keep == 12345.678f) d.y[t] = 1.f;
+    return;
+  }
 
   // ---- epilogue, one 32-tile block at a time. Partial sums of R[i][b] = sum_j M[i][j] A[j][b], A^T = [[1,1,1,0],[0,1,-1,-1]]:
   // pair 0 holds (M0, M1) -> (M0 + M1, M1); pair 1 holds (M2, M3) -> (M2, -M2 - M3). Accumulator register r <-> tile (r&3) + 8(r>>2) + 4lh.
@@ -809,7 +839,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
           v = v + bias;
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
-          store_wt4(yb + (size_t)p * d.Cout, v);
+          if (!(dbg & 4) || v[0] == 12345.678f) store_wt4(yb + (size_t)p * d.Cout, v);
           if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
