@@ -14,7 +14,7 @@ from lvae_amd import kernels as K
 from conv_bench import packed, timeit
 
 H = int(sys.argv[1])
-B, C = 256, 64
+B, C = int(os.environ.get('PHASE_B', '256')), 64
 x = torch.randn(B, H, H, C, device='cuda')
 w = packed(C, C, 3)
 g = K.ConvGeom(w, 1, 1)
@@ -26,4 +26,4 @@ K.conv2d(x, w, g, bias=b)
 K.prepared.prepare_all()
 t_p = timeit(lambda: K.conv2d(x, w, g, bias=b), 200)
 t_f = timeit(lambda: K.conv2d(x, w, g, bias=b, in_scale=sc, in_shift=sh, in_act='elu', out_scale=drop, stats_pivot=piv), 200)
-print('%dx%d wino debug=%s: plain %.1f us, fused prologue/epilogue/stats %.1f us' % (H, H, os.environ.get('LVAE_WINO_DEBUG', '0'), t_p, t_f))
+print('B=%d ' % B + '%dx%d wino debug=%s: plain %.1f us, fused prologue/epilogue/stats %.1f us' % (H, H, os.environ.get('LVAE_WINO_DEBUG', '0'), t_p, t_f))
