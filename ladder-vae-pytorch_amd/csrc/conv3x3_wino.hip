@@ -25,6 +25,11 @@
 #include "bf16_frag.h"
 #include "lvae_common.h"
 
+// build-time experiment switches of the profiling builds (tools/wino_ab.sh); the defaults are the product
+#ifndef LVAE_W1_RING
+#define LVAE_W1_RING 3
+#endif
+
 namespace lvae {
 
 struct WinoArgs {
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
     // (ring of 3, what 256 registers allow: 31.7 us with a ring of 2, 30.4 us with 3 at 256x16x16).
     const int NB = a.Npad >> 5;
     const __bf16* u3 = reinterpret_cast<const __bf16*>(a.U) + ((size_t)(co0 >> 5) * 3 * 64 + lane) * 8;
-    constexpr int BR = 3;
+    constexpr int BR = LVAE_W1_RING;
     bf16x8 bq[BR][NH][3];
     auto load_b = [&](int it, int buf) {  // it = 4 s + j
       const __bf16* p = u3 + ((dbg & 8) ? (size_t)0 : (size_t)((4 * wave + (it & 3)) * 4 + (it >> 2)) * NB * 1536);
@@ -544,12 +549,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 // Eligibility (wino2_tile): six-product form, exactly 64 tiles per workgroup whose blocks are the first and second 128 pixels of the
 // workgroup's pixel tile, and at least 256 such workgroups; everything else keeps conv3x3_wino_kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
-#ifndef LVAE_W2_SGB
-#define LVAE_W2_SGB 0
-#endif
 #ifndef LVAE_W2_PAIRSPLIT
 #define LVAE_W2_PAIRSPLIT 1
 #endif
+
 constexpr int W2_LDS_R = 8 * 2 * 32 * WLDO * 4;  // bytes of the partial-sum exchange of one block
 
 __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
@@ -752,13 +755,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
 #pragma unroll
           for (int kk = 0; kk < 6; ++kk)
             acc[m][jj][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[PA[kk]], bq[it % BR][h][PB[kk]], acc[m][jj][h], 0, 0, 0);
-#if LVAE_W2_SGB
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, LVAE_W2_SGB, 0);  // vector instructions of the next step's fragments beside it
-        }
-#endif
         if (st < 3) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) afc[q] = afn[q];

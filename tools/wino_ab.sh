@@ -12,5 +12,5 @@ IFS=';' read -ra VS <<< "$VARIANTS"
 for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; ( /opt/rocm/bin/hipcc $FLAGS $f -c conv3x3_wino.hip -o wino_$n.o && /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o $DBG/lib_$n.so $OBJS wino_$n.o ) & done
 wait
 cd $GRAFT_REPO_ROOT
-for H in ${HS:-16 32}; do for v in "${VS[@]}"; do n=${v%%=*}; echo -n "$n: "; LVAE_DISABLE_WINO2=$([ $n = old ] && echo 1 || echo 0) python tools/wino_phase.py $H $DBG/lib_$n.so 2>&1 | grep debug || true; done; done
-for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; case "$f" in *LVAE_WINO_DBG=64*) for H in ${HS:-16}; do LVAE_DISABLE_WINO2=$([ $n = old64 ] && echo 1 || echo 0) python tools/wino_stamps.py $H $DBG/lib_$n.so 2>&1 | grep -v Warn; done;; esac; done
+for H in ${HS:-16 32}; do for v in "${VS[@]}"; do n=${v%%=*}; echo -n "$n: "; LVAE_DISABLE_WINO2=$(case $n in old*) echo 1;; *) echo 0;; esac) python tools/wino_phase.py $H $DBG/lib_$n.so 2>&1 | grep debug || true; done; done
+for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; case "$f" in *LVAE_WINO_DBG=64*) for H in ${HS:-16}; do LVAE_DISABLE_WINO2=$(case $n in old*) echo 1;; *) echo 0;; esac) python tools/wino_stamps.py $H $DBG/lib_$n.so 2>&1 | grep -v Warn; done;; esac; done
