@@ -103,6 +103,41 @@ class GradAllReduce:
         self.next_bucket = 0
         self.launched = []          # bucket indices in launch order of the current step (tests look at it)
 
+    def capture_probe(self):
+        """Can a collective on the side stream be captured into a hipGraph here? Captures (and replays once) a throw-away graph holding one
+        small all-reduce between a fork and a join of the side stream — before anything of the training step is captured, so that a refusal
+        costs nothing but this probe (unwinding a half-captured training step turned out to be unsafe: round 3 measured a GPU memory fault
+        on that path). Every rank runs the probe (it contains a collective); the verdict is the minimum over ranks. Returns (ok, reason)."""
+        if not (self.on_gpu and self.capturable):
+            return False, 'backend cannot be captured'
+        dev = self.flat.device
+        t = torch.zeros(256, dtype=torch.float32, device=dev)
+        ok, reason = True, ''
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)   # eager first: the communicator must exist before anything is captured
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                cur = torch.cuda.current_stream(dev)
+                self.stream.wait_stream(cur)
+                try:
+                    with torch.cuda.stream(self.stream):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                except Exception as e:  # noqa: BLE001  (join the fork before leaving the capture, then report)
+                    ok, reason = False, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
+                cur.wait_stream(self.stream)
+            if ok:
+                g.replay()
+        except Exception as e:  # noqa: BLE001
+            ok, reason = False, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
+        torch.cuda.synchronize(dev)
+        del g
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)     # eager: every rank takes the same branch afterwards
+        if ok and float(flag.item()) == 0.0:
+            ok, reason = False, 'another rank could not capture the collective'
+        return ok, reason
+
     @property
     def active(self):
         return (self.world > 1 or self.force) and os.environ.get('LVAE_SKIP_ALLREDUCE') != '1'   # second: profiling only

@@ -49,10 +49,10 @@ class TrainStep:
         self.wgrad_group_rows = wgrad_group_rows
         self.eager_left = eager_warmup if use_graph else -1
         self.graph_a = self.graph_b = None
+        self.fallback_reason = None
         self.static_x = None
         self.static_out = None
         self._bns = None
-        self.fallback_reason = None
         self._table_ref = None
         if allreduce is not None and allreduce.world > 1:
             optimizer._state()
@@ -62,6 +62,14 @@ class TrainStep:
             self.use_graph, self.eager_left = False, -1   # gloo stages device buffers through the host: cannot be part of a graph
         self.trace = os.environ.get('LVAE_STEP_TRACE') == '1'   # diagnosis only: host-synchronised phase times on stderr
         self.overlap = allreduce is not None and allreduce.active and allreduce.overlap
+        if self.overlap and self.use_graph:
+            # can the exchange be part of the step graph? If not, the same process continues with the exchange
+            # outside the graphs: fwd+bwd graph | eager all-reduce | Adamax graph
+            ok, why = allreduce.capture_probe()
+            if not ok:
+                print('[lvae] the gradient exchange cannot be captured into the step graph (%s); keeping it outside '
+                      '(LVAE_DDP_MODE=split)' % why, file=sys.stderr, flush=True)
+                self.overlap, self.fallback_reason = False, why
         if self.overlap:
             model.grad_tracker = allreduce   # the model's segment markers report to it during backward
 
@@ -100,26 +108,13 @@ class TrainStep:
         fused = self.allreduce is None or not self.allreduce.active or self.overlap
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
-        try:
-            # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures
-            with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
-                self.static_out = self._fwd_bwd(self.static_x)
-                if fused:
-                    self.opt.step()
-        except Exception as e:  # noqa: BLE001
-            if not (self.overlap and self.allreduce is not None and self.allreduce.active and self._is_capture_error(e)):
-                raise   # a kernel / launch / shape error keeps its traceback: only a collective that refuses capture is retried
-            # keep the exchange outside the graphs (fwd+bwd graph | eager all-reduce | Adamax graph), in this same process
-            self.fallback_reason = '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
-            print('[lvae] capturing the gradient exchange failed (%s); continuing with the exchange outside the step graph '
-                  '(LVAE_DDP_MODE=split)' % self.fallback_reason, file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            self.overlap = False
-            self.model.grad_tracker = None
-            self.graph_a = self.graph_b = None
-            for bn in self.model.bn_modules():      # the aborted capture ran the Python forward once: un-count its BatchNorm forwards
-                bn._pending -= 1
-            return self._capture(x)
+        # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures.
+        # (Whether the exchange CAN be captured was settled by GradAllReduce.capture_probe() in __init__: a refusal inside this capture
+        # would leave a half-captured training step behind, and unwinding that is not safe.)
+        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
+            self.static_out = self._fwd_bwd(self.static_x)
+            if fused:
+                self.opt.step()
         if not fused:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
@@ -128,13 +123,6 @@ class TrainStep:
         # the captured prepare_all launch baked in the device address (and entry count) of the transformed-weight table: keep exactly
         # that table, and the scratch buffers its entries point to, alive and unmodified for as long as this graph can be replayed
         self._table_ref = K.prepared.pin_current()
-
-    @staticmethod
-    def _is_capture_error(e):
-        """True for errors raised because an operation is not permitted / not supported while the stream is capturing (hipGraph
-        capture invalidated, RCCL refusing a captured collective), False for everything else."""
-        msg = str(e).lower()
-        return any(k in msg for k in ('captur', 'hipgraph', 'cudagraph', 'graph', 'nccl', 'rccl', 'operation not permitted when stream'))
 
     def exchange_description(self):
         """How the gradients are exchanged in this process (bench.py's config.grad_exchange)."""

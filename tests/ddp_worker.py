@@ -3,6 +3,7 @@
   single  one rank, no process group: TrainStep (hipGraph), the reference point
   rccl1   one rank over RCCL with LVAE_FORCE_DIST=1: the N > 1 code path — completion-ordered buckets exchanged on the side stream
           while backward runs, all inside the captured graph
+  rccl1_fallback  as rccl1, but the all-reduce refuses to be captured: TrainStep must fall back to the split form in the same process
   gloo2   rank RANK of 2 over gloo, both ranks on the one GPU of the test box, eager launches (gloo cannot be captured)
   gloo2a  the same with every weight-gradient kernel on one of two side streams (async_wgrad): a bucket's exchange must wait for them
   emul2   one process playing both ranks of gloo2 one after the other: per-shard forward/backward with per-rank BatchNorm
@@ -69,6 +70,32 @@ def main():
         torch.cuda.synchronize()
         assert step.graph_a is not None and step.graph_b is None      # ONE graph: backward, exchange and Adamax together
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'launched': ar.launched})
+        torch.distributed.destroy_process_group()
+    elif mode == 'rccl1_fallback':
+        # a collective that refuses to be captured: TrainStep's capture probe finds out before the step is captured and the same process
+        # continues with the exchange outside the step graph (fwd+bwd graph | eager all-reduce | Adamax graph)
+        os.environ['LVAE_FORCE_DIST'] = '1'
+        rank, world, _ = ldist.init_from_env('nccl')
+        m, opt = build(0)
+        arena = m.pack()
+        ldist.broadcast_flat(arena.params)
+        ar = ldist.GradAllReduce(arena.grads, segments=arena.segments, bucket_mb=0.25)
+        real = torch.distributed.all_reduce
+
+        def refusing(*a, **kw):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('operation not permitted when stream is capturing (simulated by the test)')
+            return real(*a, **kw)
+
+        torch.distributed.all_reduce = refusing
+        step = TrainStep(m, opt, use_graph=True, allreduce=ar)     # its capture probe meets the refusal: split mode from the start
+        assert not step.overlap and step.fallback_reason and m.grad_tracker is None
+        losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
+        torch.cuda.synchronize()
+        torch.distributed.all_reduce = real
+        assert step.graph_a is not None and step.graph_b is not None
+        assert 'split' in step.exchange_description()
+        dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'reason': step.fallback_reason})
         torch.distributed.destroy_process_group()
     elif mode in ('gloo2', 'gloo2a'):   # gloo2a: weight-gradient kernels on side streams (async_wgrad) under the overlapped exchange
         rank, world, _ = ldist.init_from_env('gloo')

@@ -123,6 +123,23 @@ def test_forced_rccl_rank_overlapped_graph_step_matches_single_rank(tmp_path):
     assert nb >= 3 and rb['extra']['launched'] == list(range(nb))     # every bucket exchanged once, in completion order
 
 
+def test_capture_refusing_collective_falls_back_to_split_in_process(tmp_path):
+    """if the gradient exchange cannot be captured (GradAllReduce.capture_probe meets a refusal), the SAME process
+    continues with the exchange outside the step graph; parameters, BatchNorm statistics (incl. num_batches_tracked) and losses equal
+    the plain single-rank run."""
+    a, b = str(tmp_path / 'single.pt'), str(tmp_path / 'fb.pt')
+    _run('single', a, 5)
+    _run('rccl1_fallback', b, 5)
+    ra, rb = torch.load(a), torch.load(b)
+    la, lb = ra['extra']['losses'], rb['extra']['losses']
+    assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 1e-6, (la, lb)
+    assert _max_rel(rb['sd'], ra['sd']) < 1e-6
+    for k in ra['sd']:
+        if k.endswith('num_batches_tracked'):
+            assert int(ra['sd'][k]) == int(rb['sd'][k]) == 5, k
+    assert 'capturing' in rb['extra']['reason']
+
+
 @pytest.mark.parametrize('mode', ['gloo2', 'gloo2a'])
 def test_two_gloo_ranks_on_one_gpu_match_two_rank_emulation(tmp_path, mode):
     """gloo2a: weight-gradient kernels on side streams while buckets are exchanged during backward — a bucket's all-reduce
