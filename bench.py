@@ -341,6 +341,12 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and os.environ.get('LVAE_FORCE_DIST') != '1':
         self_launch(args, sys.argv[1:])   # never returns
 
+    # Native libraries write to the process's stdout too (RCCL prints a five-line version banner there when its first communicator
+    # is created): keep file descriptor 1 pointed at stderr for the whole run and give it back only for the ONE JSON line at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from lvae_amd import dist as ldist
     from lvae_amd.models.lvae import LadderVAE
     from lvae_amd.noise import PhiloxNoise
@@ -353,8 +359,8 @@ def main():
         if world > 1:
             dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({'metric': 'launch-check', 'value': float(t.item()), 'n_gpus': world, 'backend': args.backend,
-                              'self_launched': os.environ.get('LVAE_BENCH_SELF_LAUNCHED') == '1'}), flush=True)
+            os.write(json_fd, (json.dumps({'metric': 'launch-check', 'value': float(t.item()), 'n_gpus': world, 'backend': args.backend,
+                                           'self_launched': os.environ.get('LVAE_BENCH_SELF_LAUNCHED') == '1'}) + '\n').encode())
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -466,7 +472,8 @@ def main():
         log('cpu baseline on %d host cores ...' % host_cores())
         line['cpu_baseline'] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -102,6 +102,15 @@ class GradAllReduce:
         self.overlap = segments is not None and os.environ.get('LVAE_DDP_MODE', 'overlap') != 'split'
         self.next_bucket = 0
         self.launched = []          # bucket indices in launch order of the current step (tests look at it)
+        # Buckets on the GPU go through a communicator of our own (rccl.Comm): its ncclAllReduce is a plain launch on our side stream,
+        # with no ProcessGroupNCCL work objects, events or watchdog behind it — which is what makes it safe to capture (rccl.py).
+        self.comm, self.comm_error = None, None
+        if self.on_gpu and self.capturable and (self.world > 1 or self.force):
+            try:
+                from . import rccl
+                self.comm = rccl.Comm(group)
+            except Exception as e:  # noqa: BLE001  (no private communicator: the process group's collectives, never captured)
+                self.comm_error = '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
 
     def capture_probe(self):
         """Can a collective on the side stream be captured into a hipGraph here? Captures (and replays once) a throw-away graph holding one
@@ -110,10 +119,12 @@ class GradAllReduce:
         on that path). Every rank runs the probe (it contains a collective); the verdict is the minimum over ranks. Returns (ok, reason)."""
         if not (self.on_gpu and self.capturable):
             return False, 'backend cannot be captured'
+        if self.comm is None:
+            return False, 'no private RCCL communicator (%s): the process group\'s collectives are not captured' % (self.comm_error or 'not created')
         dev = self.flat.device
         t = torch.zeros(256, dtype=torch.float32, device=dev)
         ok, reason = True, ''
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)   # eager first: the communicator must exist before anything is captured
+        self._all_reduce(t)   # eager first: everything lazy inside the communicator happens before anything is captured
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         try:
@@ -122,7 +133,7 @@ class GradAllReduce:
                 self.stream.wait_stream(cur)
                 try:
                     with torch.cuda.stream(self.stream):
-                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                        self._all_reduce(t)
                 except Exception as e:  # noqa: BLE001  (join the fork before leaving the capture, then report)
                     ok, reason = False, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
                 cur.wait_stream(self.stream)
@@ -146,9 +157,15 @@ class GradAllReduce:
         self.next_bucket = 0
         self.launched = []
 
+    def _all_reduce(self, t):
+        if self.comm is not None:
+            self.comm.all_reduce_(t)            # on torch's current stream (the side stream when called from _launch_through)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def _reduce(self, k):
         lo, hi, _ = self.buckets[k]
-        dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(self.flat[lo:hi])
         self.launched.append(k)
 
     def _launch_through(self, k):

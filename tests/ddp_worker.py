@@ -64,6 +64,7 @@ def main():
         arena = m.pack()
         ldist.broadcast_flat(arena.params)
         ar = ldist.GradAllReduce(arena.grads, segments=arena.segments, bucket_mb=0.25)
+        assert ar.comm is not None, ar.comm_error          # the captured exchange never goes through ProcessGroupNCCL
         step = TrainStep(m, opt, use_graph=True, allreduce=ar)
         assert step.overlap and m.grad_tracker is ar and len(ar.buckets) >= 3
         losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
@@ -80,19 +81,20 @@ def main():
         arena = m.pack()
         ldist.broadcast_flat(arena.params)
         ar = ldist.GradAllReduce(arena.grads, segments=arena.segments, bucket_mb=0.25)
-        real = torch.distributed.all_reduce
+        assert ar.comm is not None, ar.comm_error          # buckets go through the private RCCL communicator (rccl.py)
+        real = ar.comm.all_reduce_
 
         def refusing(*a, **kw):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('operation not permitted when stream is capturing (simulated by the test)')
             return real(*a, **kw)
 
-        torch.distributed.all_reduce = refusing
+        ar.comm.all_reduce_ = refusing
         step = TrainStep(m, opt, use_graph=True, allreduce=ar)     # its capture probe meets the refusal: split mode from the start
         assert not step.overlap and step.fallback_reason and m.grad_tracker is None
         losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
         torch.cuda.synchronize()
-        torch.distributed.all_reduce = real
+        ar.comm.all_reduce_ = real
         assert step.graph_a is not None and step.graph_b is not None
         assert 'split' in step.exchange_description()
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'reason': step.fallback_reason})
