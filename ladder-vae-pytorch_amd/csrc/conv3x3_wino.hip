@@ -37,6 +37,8 @@ struct WinoArgs {
   const float* U;  // [16][8][2][Npad][4]: position, k/8, (k/4)&1, n, k&3; six-product form: bf16 [16][4 k16][Npad/32][3 pieces][64 lanes][8]
   int TH, TW, NI, tiles_h, halo_w, halo_h, halo_px, ntn, Npad, tiles_x, wt_per_img, n_wt, Cin;
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
+  lvae_bn_fold f;   // copy of *d.in_fold (f.parts == nullptr: none): BatchNorm finalize of the input in the prologue, wino_fold_bn
+  int store_pivot;  // the statistics epilogue also stores its pivot behind the partial rows (for a consumer that folds the finalize)
 };
 
 // Six-product form (conv3x3_wino_kernel<.., SPL = true>): U[p][k][n] split exactly into three bf16 pieces, stored in the B-fragment order of
@@ -153,6 +155,66 @@ __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoPrep
 
 constexpr int WLDO = 68;  // R row stride (floats)
 
+// Folded BatchNorm finalize (lvae_bn_fold, same contract as conv3x3_pos_kernel's): every workgroup reduces the producer's partial rows
+// [rows][2][C] (+ the pivot row) to the scale / shift of its input transform instead of waiting for a finalize launch of its own
+// (5 us + a launch boundary in front of a 20-30 us kernel, 196 times per step); the rows come from L2 with 16-byte loads, eight in flight
+// per thread, while the first halo slice is still on its way from HBM. Fixed summation order (thread -> (float4 of the row, row group),
+// fp32 within a group, double across groups): deterministic, and every workgroup computes identical coefficients. `writer` (one workgroup)
+// publishes (scale, shift, mean, rstd) for the backward and applies the momentum update of the running statistics.
+// scratch: [NT / 32][128] floats (may alias memory that is written only after this returns); coef: [128] = scale[64], shift[64]. C <= 64.
+template <int NT>
+__device__ __forceinline__ void wino_fold_bn(const lvae_bn_fold& f, int C, float* scratch, float* coef, int t, bool writer) {
+  constexpr int G = NT / 32;
+  const int q = t & 31, g = t >> 5, rows = f.rows;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (2 * q < C)  // float4 q of a row = [sum C][sum of squares C]
+    for (int r = g; r < rows; r += 8 * G) {
+      f32x4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r + u * G;
+        p[u] = *reinterpret_cast<const f32x4*>(f.parts + ((size_t)(rr < rows ? rr : g) * 2) * C + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + u * G < rows) s += p[u];
+    }
+  *reinterpret_cast<f32x4*>(scratch + g * 128 + 4 * q) = s;
+  __syncthreads();
+  if (t < C) {
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      sa += (double)scratch[k * 128 + t];
+      sb += (double)scratch[k * 128 + C + t];
+    }
+    const float pivot = f.parts[((size_t)rows * 2) * C + t];  // the producer's pivot, stored behind its partial rows
+    const double M = (double)f.M, inv_m = 1.0 / M, dm = sa * inv_m;
+    double m2 = sb - sa * dm;
+    if (m2 < 0.0) m2 = 0.0;
+    const double mean = (double)pivot + dm, var = m2 * inv_m;
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float gam = f.gamma ? f.gamma[t] : 1.f, bet = f.beta ? f.beta[t] : 0.f;
+    const float scl = gam * rstd, shf = bet - (float)mean * scl;
+    coef[t] = scl;
+    coef[64 + t] = shf;
+    if (writer) {
+      if (f.coef_out) {
+        f.coef_out[t] = scl;
+        f.coef_out[C + t] = shf;
+        f.coef_out[2 * C + t] = (float)mean;
+        f.coef_out[3 * C + t] = rstd;
+      }
+      if (f.running_mean) {
+        const double unbiased = f.M > 1 ? m2 / (M - 1.0) : var;
+        f.running_mean[t] = (1.f - f.momentum) * f.running_mean[t] + f.momentum * (float)mean;
+        f.running_var[t] = (1.f - f.momentum) * f.running_var[t] + f.momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // In-kernel phase stamps of the profiling builds (-DLVAE_WINO_DBG with bit 64; tools/wino_phase.sh): s_memtime per wave at the phase
 // boundaries, written to a buffer of their own that nothing else reads. Never compiled into the product.
 #if defined(LVAE_WINO_DBG) && (LVAE_WINO_DBG & 64)
@@ -247,11 +309,19 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
       hlive = live ? hlive | (1u << u) : hlive & ~(1u << u);
     }
   };
+  __shared__ __attribute__((aligned(16))) float s_coef[128];  // scale[64], shift[64] of a folded BatchNorm finalize
+  const bool folded = CIN == 64 && a.f.parts != nullptr;
+  const bool bn_in = d.in_scale != nullptr || folded;
   auto store_slice = [&](int c) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
-    if (d.in_scale && 16 * c + hc4 < a.Cin) {
-      sc = *reinterpret_cast<const f32x4*>(d.in_scale + 16 * c + hc4);
-      sh = *reinterpret_cast<const f32x4*>(d.in_shift + 16 * c + hc4);
+    if (bn_in && 16 * c + hc4 < a.Cin) {
+      if (folded) {
+        sc = *reinterpret_cast<const f32x4*>(s_coef + 16 * c + hc4);
+        sh = *reinterpret_cast<const f32x4*>(s_coef + 64 + 16 * c + hc4);
+      } else {
+        sc = *reinterpret_cast<const f32x4*>(d.in_scale + 16 * c + hc4);
+        sh = *reinterpret_cast<const f32x4*>(d.in_shift + 16 * c + hc4);
+      }
     }
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
@@ -259,7 +329,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
         f32x4 w = zero4;
         if ((hlive >> u) & 1u) {
           w = hreg[u];
-          if (d.in_scale) w = act_fwd4(w * sc + sh, d.in_act);
+          if (bn_in) w = act_fwd4(w * sc + sh, d.in_act);
         }
         *reinterpret_cast<f32x4*>(As + hlds[u] + 16 * c) = w;
       }
@@ -295,6 +365,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][j][h][r] = 0.f;
 
+  if (folded) wino_fold_bn<256>(a.f, a.Cin, smem, s_coef, t, bid == 0);  // scratch: the halo patch, written only from here on
   store_slice(0);
   load_slice(1);
   __syncthreads();
@@ -521,6 +592,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 #pragma unroll
         for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
         if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
+        // the pivot travels with the partials (row index = number of pixel tiles) for a consumer that finalizes them in its own prologue
+        if (a.store_pivot && tm == 0 && which == 0 && co0 + c < d.Cout)
+          d.stats_out[((size_t)(gridDim.x / a.ntn) * 2) * d.Cout + co0 + c] = d.stats_pivot[co0 + c];
       }
     }
   }
@@ -597,7 +671,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
     // slots beyond the patch write to a dump row of their own behind it (the LDS allocation is sized by the epilogue's exchange, far larger)
     hlds[u] = px < a.halo_px ? px * WLDA + hc4 : a.halo_px * WLDA + 4 * t;
   }
-  const bool bn_in = d.in_scale != nullptr;
+  __shared__ __attribute__((aligned(16))) float s_coef[128];  // scale[64], shift[64] of a folded BatchNorm finalize
+  const bool folded = a.f.parts != nullptr;
+  const bool bn_in = d.in_scale != nullptr || folded;
   f32x4 hreg[SLOTS];
   unsigned hlive = 0;
   auto load_slice = [&](int c) {
@@ -613,8 +689,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
   auto store_slice = [&](int c) {  // straight-line: one wave-uniform branch (fused input transform or not), selects instead of lane branches
     if (bn_in) {
       const int cc = 16 * c + hc4 < a.Cin ? 16 * c + hc4 : 0;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(d.in_scale + cc);
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(d.in_shift + cc);
+      f32x4 sc, sh;
+      if (folded) {
+        sc = *reinterpret_cast<const f32x4*>(s_coef + cc);
+        sh = *reinterpret_cast<const f32x4*>(s_coef + 64 + cc);
+      } else {
+        sc = *reinterpret_cast<const f32x4*>(d.in_scale + cc);
+        sh = *reinterpret_cast<const f32x4*>(d.in_shift + cc);
+      }
 #pragma unroll
       for (int u = 0; u < SLOTS; ++u) {
         f32x4 w = act_fwd4(hreg[u] * sc + sh, d.in_act);
@@ -665,6 +747,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][j][h][r] = 0.f;
 
+  if (folded) wino_fold_bn<512>(a.f, a.Cin, smem, s_coef, t, bid == 0);  // scratch: the halo patch, written only from here on
   store_slice(0);
   load_slice(1);
   __syncthreads();
@@ -868,6 +951,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
 #pragma unroll
       for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
       if (co0 + c < d.Cout) d.stats_out[((size_t)tm * 2 + which) * d.Cout + co0 + c] = v;
+      // the pivot travels with the partials (row index = number of pixel tiles) for a consumer that finalizes them in its own prologue
+      if (a.store_pivot && tm == 0 && which == 0 && co0 + c < d.Cout)
+        d.stats_out[((size_t)(gridDim.x / a.ntn) * 2) * d.Cout + co0 + c] = d.stats_pivot[co0 + c];
     }
   }
 }
@@ -951,12 +1037,32 @@ static bool wino_tile(const lvae_conv_desc* d, WinoTile& w) {
   return true;
 }
 
-// 0: this kernel would not run for d; LVAE_VARIANT_WINO_F32 / LVAE_VARIANT_WINO_SIX otherwise
+static size_t wino_lds_bytes(const lvae_conv_desc* d, const WinoTile& w) {
+  size_t lds = (size_t)w.NI * (w.TH + 2) * (d->W + 2) * (wino_kpad(d) + 4) * sizeof(float);
+  const size_t lds_r = w.mt == 2 ? (size_t)W2_LDS_R : (size_t)4 * 2 * 32 * WLDO * sizeof(float);
+  return lds < lds_r ? lds_r : lds;
+}
+
+// 0: this kernel would not run for d (every condition conv3x3_wino_try checks); LVAE_VARIANT_WINO_F32 / LVAE_VARIANT_WINO_SIX otherwise
 int conv3x3_wino_variant(const lvae_conv_desc* d) {
-  if (d->workspace == nullptr || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
+  if (d->workspace == nullptr || !al16w2(d->workspace) || !conv3x3_wino_eligible(d) ||
+      (size_t)d->workspace_bytes < conv3x3_wino_workspace(d))
+    return 0;
   WinoTile w;
-  if (!wino_tile(d, w)) return 0;
+  if (!wino_tile(d, w) || wino_lds_bytes(d, w) > 159 * 1024) return 0;
   return wino_split_form(d) ? LVAE_VARIANT_WINO_SIX : LVAE_VARIANT_WINO_F32;
+}
+
+// Folded BatchNorm finalize of the input (lvae_bn_fold, wino_fold_bn): 64-channel inputs, and launches of at most two workgroups per CU
+// (every workgroup re-reads the producer's partial rows from L2: 128-256 KB each; with four rounds per CU a finalize launch is cheaper)
+bool conv3x3_wino_folds(const lvae_conv_desc* d) {
+  static const bool off = tune("LVAE_DISABLE_WINO_FOLD", 0) != 0;  // A/B switch (tuning builds only)
+  if (off || d->C1 > 64 || conv3x3_wino_variant(d) == 0) return false;
+  WinoTile w;
+  if (!wino_tile(d, w)) return false;
+  const bool narrow = w.mt == 1 && wino_narrow(d, w.TH, w.NI);
+  const int64_t wgs = (int64_t)((d->N + w.NI - 1) / w.NI) * (d->H / w.TH) * (narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64);
+  return wgs <= 512;
 }
 
 // rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
@@ -964,7 +1070,7 @@ int conv3x3_wino_stats_rows(const lvae_conv_desc* d) {
   if (d->workspace == nullptr || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
   WinoTile w;
   if (!wino_tile(d, w)) return 0;
-  if ((size_t)w.NI * (w.TH + 2) * (d->W + 2) * ((d->C1 <= 64 ? 64 : 128) + 4) * sizeof(float) > 160 * 1024) return 0;
+  if (wino_lds_bytes(d, w) > 159 * 1024) return 0;
   return ((d->N + w.NI - 1) / w.NI) * (d->H / w.TH);
 }
 
@@ -1000,17 +1106,23 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   a.m_wt_per_img = fastdiv_magic(a.wt_per_img);
   const int kpad = wino_kpad(d);
   a.Cin = Cin;
-  size_t lds = (size_t)a.halo_px * (kpad + 4) * sizeof(float);
-  const size_t lds_r = mt == 2 ? (size_t)W2_LDS_R : (size_t)4 * 2 * 32 * WLDO * sizeof(float);
-  if (lds < lds_r) lds = lds_r;
-  if (lds > 160 * 1024) return -1000;
+  const size_t lds = wino_lds_bytes(d, wtile);
+  if (lds > 159 * 1024) return -1000;  // + 512 bytes of static LDS (s_coef)
+  const bool folds = conv3x3_wino_folds(d);
+  a.f = lvae_bn_fold{};
+  if (d->in_fold != nullptr) {
+    if (!folds) return -1000;  // lvae_conv2d_f32 has checked lvae_conv2d_folds_bn_finalize(d); never run a kernel that ignores the fold
+    a.f = *d->in_fold;
+  }
+  a.d.in_fold = nullptr;
+  a.store_pivot = folds && d->stats_out != nullptr && d->stats_mode == LVAE_STATS_BN_FWD;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;

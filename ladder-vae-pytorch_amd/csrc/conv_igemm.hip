@@ -388,6 +388,7 @@ extern "C" size_t lvae_conv2d_workspace(const lvae_conv_desc* d) {
 
 namespace lvae {
 int conv3x3_wino_variant(const lvae_conv_desc* d);
+bool conv3x3_wino_folds(const lvae_conv_desc* d);
 }
 
 extern "C" int32_t lvae_conv2d_variant(const lvae_conv_desc* d) {
@@ -434,7 +435,9 @@ extern "C" int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d) {
 
 extern "C" int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d) {
   if (d == nullptr || tune("LVAE_DISABLE_HALO", 0) != 0) return 0;
-  return conv3x3_pos_eligible(d) ? 1 : 0;
+  if (conv3x3_pos_eligible(d)) return 1;
+  const int v = lvae_conv2d_variant(d);
+  return (v == LVAE_VARIANT_WINO_F32 || v == LVAE_VARIANT_WINO_SIX) && conv3x3_wino_folds(d) ? 1 : 0;
 }
 
 extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
@@ -451,9 +454,15 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
                    lvae_conv2d_variant(d) == LVAE_VARIANT_BF16_DIRECT,
                LVAE_EINVAL, "lvae_conv2d_f32: bf16-stored tensors need the bf16 3x3 kernel (precision LVAE_PREC_BF16, lvae_conv2d_variant(d) == "
                             "LVAE_VARIANT_BF16_DIRECT)");
-  LVAE_REQUIRE(d->in_fold == nullptr || (!halo_off && conv3x3_pos_eligible(d) && d->in_fold->parts != nullptr &&
-                                          d->in_fold->rows > 0 && d->in_fold->M > 0 && d->in_scale == nullptr),
-               LVAE_EINVAL, "lvae_conv2d_f32: in_fold set but lvae_conv2d_folds_bn_finalize(d) == 0 (or bad parts / rows / M, or in_scale given too)");
+  if (d->in_fold != nullptr) {
+    lvae_conv_desc t = *d;  // the kernel choice is made on the descriptor without its fold (as the caller asked lvae_conv2d_folds_bn_finalize)
+    t.in_fold = nullptr;
+    LVAE_REQUIRE(lvae_conv2d_folds_bn_finalize(&t) != 0 && d->in_fold->parts != nullptr &&
+                     (reinterpret_cast<uintptr_t>(d->in_fold->parts) & 15) == 0 && d->C1 % 4 == 0 && d->in_fold->rows > 0 &&
+                     d->in_fold->M > 0 && d->in_scale == nullptr,
+                 LVAE_EINVAL,
+                 "lvae_conv2d_f32: in_fold set but lvae_conv2d_folds_bn_finalize(d) == 0 (or bad parts / rows / M, or in_scale given too)");
+  }
   if (!halo_off) {
     int hr = conv3x3_pos_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;
@@ -464,6 +473,7 @@ extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
     }
     hr = conv3x3_wino_try(d, d->workspace, (size_t)d->workspace_bytes, (hipStream_t)stream);
     if (hr != -1000) return hr;
+    LVAE_REQUIRE(d->in_fold == nullptr, LVAE_EINVAL, "lvae_conv2d_f32: no kernel took the folded BatchNorm finalize (in_fold)");
     hr = conv3x3_halo_try(d, (hipStream_t)stream);
     if (hr != -1000) return hr;
     hr = conv1x1_try(d, nullptr, nullptr, 0, (hipStream_t)stream);

@@ -668,12 +668,18 @@ def test_conv3x3_position_major_small_images(K, case):
     assert rel(nchw(dx), dref) < 2e-6
 
 
-@pytest.mark.parametrize('case', [(256, 64, 4, 4), (96, 64, 2, 2), (40, 32, 4, 4)])
-def test_bn_finalize_folded_into_the_consuming_convolution(K, case):
+@pytest.mark.parametrize('case', [(256, 64, 4, 4), (96, 64, 2, 2), (40, 32, 4, 4),                   # position-major kernel
+                                  (256, 64, 16, 16), (256, 64, 8, 8), (64, 64, 24, 24), (96, 48, 16, 16)])  # Winograd kernels: 256-pixel
+                                  # six-product, 32-channel fp32, 128-pixel six-product, 48 of 64 padded channels
+def test_bn_finalize_folded_into_the_consuming_convolution(K, case, monkeypatch):
     """lvae_bn_fold: conv1 writes BatchNorm partials (+ its pivot) of its output; conv2 finalizes them in its prologue, publishes
     (scale, shift, mean, rstd) and updates the running statistics — against nn.BatchNorm2d semantics (lib/nn.py:80-81)."""
     import types
     N, Cc, H, W = case
+
+    def no_finalize_launch(*a, **k):
+        raise AssertionError('the consuming convolution did not take the folded finalize')
+    monkeypatch.setattr(K, 'bn_finalize_parts', no_finalize_launch)
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cc, H, W, generator=g)
     w1 = torch.randn(Cc, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)
@@ -690,7 +696,7 @@ def test_bn_finalize_folded_into_the_consuming_convolution(K, case):
     rmr, rvr = rm0.clone(), rv0.clone()
     h = F.batch_norm(r1, rmr, rvr, gamma, beta, True, 0.1, 1e-5)
     r2 = F.conv2d(F.elu(h), w2, None, padding=1)
-    assert rel(nchw(y2), r2) < 5e-6
+    assert rel(nchw(y2), r2) < (5e-6 if H * W <= 16 else 2e-5)
     torch.testing.assert_close(mean.cpu(), r1.mean((0, 2, 3)), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(rstd.cpu(), 1 / torch.sqrt(r1.var((0, 2, 3), unbiased=False) + 1e-5), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(sc.cpu(), gamma * rstd.cpu(), rtol=1e-6, atol=1e-7)
