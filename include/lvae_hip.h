@@ -84,7 +84,10 @@ const char* lvae_last_error(void);
  * holds that producer's pivot (kernels for which lvae_conv2d_folds_bn_finalize != 0, and the gate kernel, store it) — computes
  * scale / shift in its prologue (M = N*H*W elements per channel; gamma / beta may be NULL = 1 / 0), publishes (scale, shift,
  * mean, rstd) to coef_out [4][C1] for the backward and applies the momentum update to running_mean / running_var (may be NULL).
- * Only for descriptors with lvae_conv2d_folds_bn_finalize(d) != 0. */
+ * Only for descriptors with lvae_conv2d_folds_bn_finalize(d) != 0 (asked on the descriptor WITHOUT in_fold): the position-major
+ * kernel of the <= 4x4 levels and the Winograd kernels with at most 64 input channels and at most 512 workgroups. parts must be
+ * 16-byte aligned, C1 % 4 == 0. A kernel with lvae_conv2d_folds_bn_finalize(d) != 0 also WRITES rows + 1 rows of statistics
+ * (stats_out, LVAE_STATS_BN_FWD): size that buffer accordingly. */
 typedef struct lvae_bn_fold {
   const float* parts;
   int32_t rows;

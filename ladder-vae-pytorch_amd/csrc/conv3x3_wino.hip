@@ -1062,7 +1062,8 @@ bool conv3x3_wino_folds(const lvae_conv_desc* d) {
   if (!wino_tile(d, w)) return false;
   const bool narrow = w.mt == 1 && wino_narrow(d, w.TH, w.NI);
   const int64_t wgs = (int64_t)((d->N + w.NI - 1) / w.NI) * (d->H / w.TH) * (narrow ? (d->Cout + 31) / 32 : (d->Cout + 63) / 64);
-  return wgs <= 512;
+  static const int64_t max_wgs = tune("LVAE_WINO_FOLD_MAX_WGS", 512);
+  return wgs <= max_wgs;
 }
 
 // rows of BatchNorm partials a launch writes (one per pixel tile), 0 when this kernel would not run
