@@ -4,6 +4,7 @@ non-finite / extreme operands (include/lvae_hip.h, `precision` and `form`):
  * Winograd position GEMMs on the fp32 MFMA (form = LVAE_FORM_F32_MFMA) vs the six-product form on the bf16 MFMA (default), forward + dgrad
  * persistent gate forward vs a float64 reference, incl. its BatchNorm partials
  * fused gate backward: six-product (default) vs fp32 MFMA
+ * BatchNorm finalize folded into the consuming convolution's prologue (lvae_bn_fold) vs the finalize launch + in_scale / in_shift
  * +-inf, NaN, values beyond the bf16 range (3.39e38 .. FLT_MAX) and denormals through the six-product kernels
 """
 import random
@@ -116,6 +117,47 @@ def test_fused_gate_backward_forms_agree_on_random_shapes(K):
                 res.append((dx.clone(), dw.clone(), db.clone()))
         e = max(rel(res[1][0], res[0][0]), rel(res[1][1], res[0][1]), rel(res[1][2], res[0][2]))
         assert e < 5e-6, ('gate bwd', N, H, e)
+
+def test_folded_bn_finalize_agrees_with_the_finalize_launch_on_random_shapes(K):
+    """lvae_bn_fold (position-major and Winograd kernels) against lvae_bn_finalize_parts_f32 + in_scale / in_shift on the same partial
+    sums: output, published coefficients and running statistics (nn.BatchNorm2d of lib/nn.py:80-81; both are restatements of one
+    formula with different summation orders, so they agree to fp32 rounding, not bitwise)."""
+    import types
+    random.seed(7)
+    torch.manual_seed(7)
+    lib = K._C.load()
+    folded = 0
+    for it in range(24):
+        H = W = random.choice([2, 4, 8, 16, 24])
+        C = random.choice([36, 48, 64]) if H >= 8 else random.choice([32, 64])
+        lo = max(1, (16384 + H * W - 1) // (H * W)) if H >= 8 else 8
+        N = random.randint(lo, max(lo + 1, 70000 // (H * W)))
+        Co = random.choice([32, 64])
+        x = torch.randn(N, H, W, C, device='cuda')
+        w1, w2 = packed(C, C, 3), packed(Co, C, 3)
+        g1, g2 = K.ConvGeom(w1, 1, 1), K.ConvGeom(w2, 1, 1)
+        gamma, beta = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.2
+        rm0, rv0 = torch.randn(C, device='cuda') * 0.1, torch.rand(C, device='cuda') + 0.5
+
+        def bn():
+            return types.SimpleNamespace(weight=gamma, bias=beta, running_mean=rm0.clone(), running_var=rv0.clone(), eps=1e-5, momentum=0.1)
+        pivot = rm0.clone()
+        y1, parts = K.conv2d(x, w1, g1, stats_pivot=pivot)
+        if parts is None:
+            continue
+        M = N * H * W
+        bn_a, bn_b = bn(), bn()
+        ya, _, coef_a = K.conv2d(y1, w2, g2, in_act='elu', in_bn=(parts, pivot, bn_a))
+        coef_b = K.bn_finalize_parts(parts.rows_view(), M, pivot, gamma, beta, bn_b.running_mean, bn_b.running_var, 1e-5, 0.1)
+        yb = K.conv2d(y1, w2, g2, in_scale=coef_b[0], in_shift=coef_b[1], in_act='elu')
+        folded += int(parts.has_pivot)
+        assert rel(ya, yb) < 2e-6, ('fold output', N, H, C, Co)
+        for a, b, what in zip(coef_a, coef_b, ('scale', 'shift', 'mean', 'rstd')):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7, msg=lambda m: '%s %s: %s' % (what, (N, H, C, Co), m))
+        torch.testing.assert_close(bn_a.running_mean, bn_b.running_mean, rtol=2e-6, atol=2e-7)
+        torch.testing.assert_close(bn_a.running_var, bn_b.running_var, rtol=2e-6, atol=2e-7)
+    assert folded >= 12, folded   # most of the drawn shapes take the folded path (has_pivot <=> lvae_conv2d_folds_bn_finalize)
+
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
