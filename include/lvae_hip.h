@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 13
+#define LVAE_ABI_VERSION 14
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -219,6 +219,78 @@ size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d);
 int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
                                     float* dw, int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, size_t workspace_bytes,
                                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused residual-block kernels of the low-resolution levels (H*W a divisor of 64: 8x8, 4x4, 2x2 ...), "whole-image tiles"
+ * (csrc/resblock_img.hip). A workgroup's 64 / 128 GEMM rows are whole images, so the 3x3 convolution of `d` (64 -> 64 channels,
+ * stride 1, pad 1, fp32 tensors) can take its input from — and hand its output to — the neighbouring ops of a residual block
+ * (lib/nn.py:78-99,118-126) through LDS instead of through memory and separate launches:
+ *
+ *   prologue  LVAE_RB_PRO_AFFINE    T(x) = in_act(x*in_scale + in_shift), exactly lvae_conv2d_f32's input transform; d->in_fold works too
+ *             LVAE_RB_PRO_BN_APPLY  d->x = dh, the gradient w.r.t. h = act(BN(bwd_x)); the input of the convolution (a dgrad descriptor) is
+ *                                   the training-mode BatchNorm backward of lvae_affine_act_bwd_parts_f32 — partial rows bwd_parts
+ *                                   [bwd_rows][2][64] written by the producer of dh (stats_mode LVAE_STATS_BN_BWD), coefficient block
+ *                                   bwd_coef [4][64], bwd_M = N*H*W, dgamma / dbeta accumulated by workgroup 0 — times the Dropout2d mask
+ *                                   pro_drop [N][64]; also stored to xt_out [N,H,W,64] (the weight gradient of the producer reads it)
+ *             LVAE_RB_PRO_GATE_BWD  the input of the convolution is the GateLayer2d backward of lvae_conv1x1_gate_bwd_f32: dab from
+ *                                   (dout [M][64], ab_in [M][128]) — stored to dab when non-NULL — then (dab . gate_w^T) * pro_drop, stored to xt_out
+ *   epilogue  LVAE_RB_EPI_PLAIN     y = (conv + bias) * out_scale and the statistics epilogue of lvae_conv2d_f32 (stats_out: lvae_resblock_conv_rows(d)
+ *                                   rows, plus one pivot row behind them for LVAE_STATS_BN_FWD)
+ *             LVAE_RB_EPI_GATE      (forward prologue only) y as above, then lvae_conv1x1_gate_f32 on it inside the same launch: ab [M][128]
+ *                                   (optional), out = act(a) * sigmoid(b) + res, BatchNorm partials of out in out_stats [rows + 1][2][64]
+ *
+ * gate_w: element (reduction index k, output column n) at gate_w[k * gate_w_sk + n * gate_w_sn] — forward: k = input channel (64),
+ * n = gate channel (128); backward: k = gate channel (128), n = input channel (64).
+ * d->workspace: lvae_resblock_conv_workspace(d) bytes of pre-split weights, private to (w, orientation) like lvae_conv2d_f32's; filled by the
+ * launch itself unless d->workspace_ready, or by lvae_conv2d_prepare_weights from a table entry written by lvae_resblock_conv_prepare_entry.
+ * Arithmetic by d->precision: LVAE_PREC_F32 = six exact bf16-piece products per fp32 product (as LVAE_FORM_SIX_PRODUCT), LVAE_PREC_BF16 =
+ * bf16 operands. lvae_resblock_conv_rows(d) == 0: shape not supported (use the one-kernel-per-op entry points).
+ * replaces: lib/nn.py:80-89 (BatchNorm + activation + conv + Dropout2d), :118-126 + :99 (GateLayer2d + residual) and their autograd.
+ * ---------------------------------------------------------------------------------------------------------- */
+enum { LVAE_RB_PRO_AFFINE = 0, LVAE_RB_PRO_BN_APPLY = 1, LVAE_RB_PRO_GATE_BWD = 2 };
+enum { LVAE_RB_EPI_PLAIN = 0, LVAE_RB_EPI_GATE = 1 };
+typedef struct lvae_rb_ext {
+  int32_t prologue, epilogue; /* LVAE_RB_PRO_*, LVAE_RB_EPI_* */
+  const float* gate_w;    /* the 1x1 gate weight: only read when the pre-split copy below is not ready */
+  int64_t gate_w_sk, gate_w_sn;
+  void* gate_ws;          /* lvae_resblock_gate_workspace() bytes, private to (gate_w, direction): the pre-split gate weights */
+  int64_t gate_ws_bytes;
+  int32_t gate_ws_ready;  /* non-zero: gate_ws was written by lvae_conv2d_prepare_weights (table entry: lvae_resblock_gate_prepare_entry) after the last change of gate_w */
+  const float* gate_bias; /* [128] or NULL (forward) */
+  int32_t act;            /* activation of the gate (LVAE_ACT_*) */
+  const float* res;       /* [M][64] or NULL */
+  float* ab;              /* [M][128] or NULL */
+  float* out;             /* [M][64] */
+  float* out_stats;       /* NULL or [rows + 1][2][64] */
+  const float* out_stats_pivot;
+  const float* dout;      /* gate backward: [M][64] */
+  const float* ab_in;     /* [M][128] */
+  float* dab;             /* [M][128] or NULL */
+  const float* bwd_parts; /* BatchNorm-apply prologue */
+  int32_t bwd_rows;
+  int32_t bwd_act;
+  int64_t bwd_M;
+  const float* bwd_coef;  /* [4][64]: scale, shift, mean, rstd */
+  const float* bwd_x;     /* [M][64] */
+  float* dgamma;          /* [64] accumulated, or NULL */
+  float* dbeta;
+  const float* pro_drop;  /* [N][64] or NULL */
+  float* xt_out;          /* [M][64] or NULL */
+  /* Optional L2 warm-up for the launch that FOLLOWS this one on the stream: up to two byte ranges (its pre-split weights — they are different
+   * for every convolution of a step, i.e. cold in every XCD's L2 when their kernel starts) that this launch's workgroups touch once per
+   * XCD while they wait for their own operands. Speed only: the ranges are read, never interpreted. */
+  const void* pf_ptr[2];
+  int64_t pf_bytes[2];
+} lvae_rb_ext;
+/* Pre-split copy of a gate weight for lvae_resblock_conv_f32: `g` describes the 1x1 convolution in the direction it is used (forward:
+ * C1 = 64, Cout = 128, w_sk / w_sn = strides of the input / gate channel; backward: C1 = 128, Cout = 64, strides swapped); only C1, Cout, w,
+ * w_sk, w_sn, precision and workspace are read. */
+size_t lvae_resblock_gate_workspace(const lvae_conv_desc* g);
+int lvae_resblock_gate_prepare_entry(const lvae_conv_desc* g, void* entry);
+int32_t lvae_resblock_conv_rows(const lvae_conv_desc* d);
+size_t lvae_resblock_conv_workspace(const lvae_conv_desc* d);
+int lvae_resblock_conv_prepare_entry(const lvae_conv_desc* d, void* entry);
+int lvae_resblock_conv_f32(const lvae_conv_desc* d, const lvae_rb_ext* ext, void* stream);
 
 /* Weight / bias gradient of the convolution described by `d` (d->y is unused, d->w gives only the strides):
  *   dw[tap,k,n] += sum_{n,oh,ow} T(x)[n,ih,iw,k] * dy[n,oh,ow,n]     db[n] += sum dy[..,n]

@@ -46,7 +46,20 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
-ABI_VERSION = 13  # LVAE_ABI_VERSION of include/lvae_hip.h
+class RbExt(C.Structure):
+    """mirror of struct lvae_rb_ext"""
+    _fields_ = [('prologue', C.c_int32), ('epilogue', C.c_int32), ('gate_w', C.c_void_p), ('gate_w_sk', C.c_int64), ('gate_w_sn', C.c_int64),
+                ('gate_ws', C.c_void_p), ('gate_ws_bytes', C.c_int64), ('gate_ws_ready', C.c_int32), ('gate_bias', C.c_void_p), ('act', C.c_int32), ('res', C.c_void_p), ('ab', C.c_void_p), ('out', C.c_void_p),
+                ('out_stats', C.c_void_p), ('out_stats_pivot', C.c_void_p), ('dout', C.c_void_p), ('ab_in', C.c_void_p), ('dab', C.c_void_p),
+                ('bwd_parts', C.c_void_p), ('bwd_rows', C.c_int32), ('bwd_act', C.c_int32), ('bwd_M', C.c_int64), ('bwd_coef', C.c_void_p),
+                ('bwd_x', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('pro_drop', C.c_void_p), ('xt_out', C.c_void_p),
+                ('pf_ptr', C.c_void_p * 2), ('pf_bytes', C.c_int64 * 2)]
+
+
+RB_PRO_AFFINE, RB_PRO_BN_APPLY, RB_PRO_GATE_BWD = 0, 1, 2
+RB_EPI_PLAIN, RB_EPI_GATE = 0, 1
+
+ABI_VERSION = 14  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -69,6 +82,12 @@ SIGNATURES = {
     'lvae_conv1x1_gate_bwd_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
     'lvae_conv1x1_gate_bwd_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv1x1_gate_bwd_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _L, _L, _P, _P, _Z, _P]),
+    'lvae_resblock_gate_workspace': (_Z, [C.POINTER(ConvDesc)]),
+    'lvae_resblock_gate_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_resblock_conv_rows': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_resblock_conv_workspace': (_Z, [C.POINTER(ConvDesc)]),
+    'lvae_resblock_conv_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_resblock_conv_f32': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(RbExt), _P]),
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_bf16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),

@@ -84,4 +84,16 @@ __device__ __forceinline__ void split8_3(const f32x4 lo, const f32x4 hi, bf16x8 
   for (int q = 0; q < 3; ++q) af[q] = __builtin_bit_cast(bf16x8, w[q]);
 }
 
+// One entry of the batched weight pre-transform table (lvae_conv2d_prepare_weights): the same 64 bytes as the Winograd entry of
+// conv3x3_wino.hip. kind: 1 | 3 = planes of a 3x3 weight for conv3x3_bf16.hip / resblock_img.hip; 33 | 35 = 32 + planes of a 1x1 gate weight
+// for resblock_img.hip; 0 | 16 = Winograd (conv3x3_wino.hip)
+struct BfPrepEntry {
+  const float* w;
+  __bf16* U;
+  int64_t stap, sk, sn;
+  int32_t K, N, Npad, flip;
+  int32_t Kpad, kind;
+};
+static_assert(sizeof(BfPrepEntry) == 64, "entry layout is part of the C ABI (lvae_conv2d_prepare_entry)");
+
 }  // namespace lvae

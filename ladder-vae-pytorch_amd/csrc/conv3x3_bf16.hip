@@ -679,15 +679,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
 static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- weight pre-split: piece `plane` of w[tap][k][n] (any strides) in MFMA B-fragment order, zero beyond K / N
-struct BfPrepEntry {   // same 64 bytes as the Winograd entry of conv3x3_wino.hip (lvae_conv2d_prepare_entry); kind = planes (1 | 3)
-  const float* w;
-  __bf16* U;
-  int64_t stap, sk, sn;
-  int32_t K, N, Npad, flip;
-  int32_t Kpad, kind;
-};
-static_assert(sizeof(BfPrepEntry) == 64, "entry layout is part of the C ABI (lvae_conv2d_prepare_entry)");
-
 __device__ __forceinline__ void bf_prep_element(const BfPrepEntry& e, int idx) {
   // idx -> (n, k): consecutive threads take consecutive k (the destination rows are k-contiguous)
   const int k = idx & 63, n = idx >> 6;
@@ -705,11 +696,33 @@ __device__ __forceinline__ void bf_prep_element(const BfPrepEntry& e, int idx) {
   }
 }
 
-__global__ __launch_bounds__(256) void bf_weight_kernel(BfPrepEntry e) { bf_prep_element(e, blockIdx.x * 256 + threadIdx.x); }
+// 1x1 gate convolution of the fused residual-block kernels (resblock_img.hip), kind = 32 + planes: w[k][n] (K <= 128 reduction channels,
+// N <= 128 outputs, any strides) as planes in fragment order [k-step K/16][32-column tile N/32][plane][lane = (k % 16 / 8) * 32 + n % 32][k % 8]
+__device__ __forceinline__ void gate_prep_element(const BfPrepEntry& e, int idx) {
+  const int planes = e.kind & 31;
+  const int k = idx % e.K, n = idx / e.K;
+  if (n >= e.N) return;
+  float r = e.w[(int64_t)k * e.sk + (int64_t)n * e.sn];
+  __bf16* dst = e.U + ((size_t)((k >> 4) * (e.N >> 5) + (n >> 5)) * planes) * 512 + (((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7);
+  for (int p = 0; p < planes; ++p) {
+    const __bf16 b = (__bf16)r;
+    dst[(size_t)p * 512] = b;
+    r -= (float)b;
+  }
+}
+
+__global__ __launch_bounds__(256) void bf_weight_kernel(BfPrepEntry e) {
+  if (e.kind & 32) gate_prep_element(e, blockIdx.x * 256 + threadIdx.x);
+  else bf_prep_element(e, blockIdx.x * 256 + threadIdx.x);
+}
 
 // the entries of a batched pre-transform table (lvae_conv2d_prepare_weights) whose kind != 0; the Winograd kernel takes the others
 __global__ __launch_bounds__(256) void bf_weight_batched_kernel(const BfPrepEntry* __restrict__ entries) {
   const BfPrepEntry e = entries[blockIdx.y];
+  if (e.kind == 33 || e.kind == 35) {   // 1x1 gate weights of the fused residual-block kernels
+    gate_prep_element(e, blockIdx.x * 256 + threadIdx.x);
+    return;
+  }
   if (e.kind != 1 && e.kind != 3) return;   // 0: Winograd fp32, 16: Winograd six-product form (conv3x3_wino.hip)
   bf_prep_element(e, blockIdx.x * 256 + threadIdx.x);
 }
@@ -739,6 +752,41 @@ void conv3x3_bf16_prep_entry(const lvae_conv_desc* d, int split, void* entry) {
   e.Kpad = 64;
   e.kind = split;
   memcpy(entry, &e, sizeof(e));
+}
+
+// one launch that writes the pre-split planes of ONE descriptor (the fallback of a launch whose workspace is not ready; the batched
+// form above is what a training step uses)
+// table entry / single launch for a 1x1 gate convolution d (C1 = reduction channels, Cout = outputs): planes = 1 | 3
+size_t resblock_gate_ws_bytes(const lvae_conv_desc* d, int planes) { return (size_t)d->C1 * d->Cout * planes * sizeof(__bf16); }
+void resblock_gate_prep_entry(const lvae_conv_desc* d, int planes, void* entry) {
+  BfPrepEntry e;
+  e.w = d->w;
+  e.U = static_cast<__bf16*>(d->workspace);
+  e.stap = 0;
+  e.sk = d->w_sk;
+  e.sn = d->w_sn;
+  e.K = d->C1;
+  e.N = d->Cout;
+  e.Npad = d->Cout;
+  e.flip = 0;
+  e.Kpad = d->C1;
+  e.kind = 32 + planes;
+  memcpy(entry, &e, sizeof(e));
+}
+int resblock_gate_prepare_single(const lvae_conv_desc* d, int planes, hipStream_t s) {
+  BfPrepEntry e;
+  resblock_gate_prep_entry(d, planes, &e);
+  hipLaunchKernelGGL(bf_weight_kernel, dim3((e.K * e.N + 255) / 256), dim3(256), 0, s, e);
+  LVAE_LAUNCH_CHECK("gate_weight");
+  return 0;
+}
+
+int conv3x3_bf16_prepare_single(const lvae_conv_desc* d, int split, hipStream_t s) {
+  BfPrepEntry e;
+  conv3x3_bf16_prep_entry(d, split, &e);
+  hipLaunchKernelGGL(bf_weight_kernel, dim3((e.Npad * 64 + 255) / 256), dim3(256), 0, s, e);
+  LVAE_LAUNCH_CHECK("bf_weight");
+  return 0;
 }
 
 static size_t bf_lds_bytes(int split, int halo_px, int bm) {

@@ -10,7 +10,7 @@ import weakref
 import torch
 
 from . import _C
-from ._C import ACT, BnFold, ConvDesc, GATHER_CONV, GATHER_TRANSPOSED, PREC_BF16, PREC_F32, call, ptr, stream_ptr
+from ._C import ACT, BnFold, ConvDesc, RbExt, GATHER_CONV, GATHER_TRANSPOSED, PREC_BF16, PREC_F32, call, ptr, stream_ptr
 
 _ws_cache = {}
 
@@ -152,8 +152,8 @@ class _PreparedWeights:
             self.table = None
         return len(dead)
 
-    def attach(self, d, weight, device, need):
-        key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, int(need), device.index)   # `need` tells the transform kinds apart
+    def attach(self, d, weight, device, need, entry_fn='lvae_conv2d_prepare_entry'):
+        key = (d.w, d.w_sk, d.w_sn, d.gather, d.Cout, int(need), device.index, entry_fn)   # `need` / entry_fn tell the transform kinds apart
         ent = self.entries.get(key)
         if ent is not None and not self._alive(ent):   # the address was recycled for another tensor
             del self.entries[key]
@@ -163,9 +163,9 @@ class _PreparedWeights:
             ent = {'weight': weakref.ref(weight), 'base': weight.data_ptr(), 'U': torch.empty(int(need), dtype=torch.uint8, device=device), 'stamp': None, 'entry': None}
             d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
             raw = (C.c_char * _C.load().lvae_conv2d_prepare_entry_bytes())()
-            call('lvae_conv2d_prepare_entry', C.byref(d), C.cast(raw, C.c_void_p))
+            call(entry_fn, C.byref(d), C.cast(raw, C.c_void_p))
             ent['entry'] = bytes(raw)
-            ent['cout'] = d.Cout
+            ent['cout'] = max(d.Cout, d.C1) if entry_fn == 'lvae_resblock_gate_prepare_entry' else d.Cout   # threads per entry of the batched launch
             self.entries[key] = ent
             self.table = None
         d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
@@ -179,7 +179,7 @@ class _PreparedWeights:
             return 0
         by_dev = {}
         for k, e in self.entries.items():
-            by_dev.setdefault(k[-1], []).append(e)
+            by_dev.setdefault(k[6], []).append(e)
         if self.table is None:
             if torch.cuda.is_current_stream_capturing():
                 return 0  # the table upload is a host copy: convolutions transform their own weights until an eager step built it
@@ -392,6 +392,201 @@ def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scal
     call('lvae_conv1x1_gate_bwd_wgrad_f32', C.byref(d), ptr(dout), ptr(ab), ptr(y), ACT[act], ptr(dweight), g.s_ci, g.s_co, ptr(dbias),
          ws.data_ptr(), ws.numel(), stream_ptr())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Fused residual-block launches of the low-resolution levels (csrc/resblock_img.hip, lvae_resblock_conv_f32)
+def _rb_desc(x_like, weight, g, dgrad, y=None, bias=None, in_scale=None, in_shift=None, in_act=None, out_scale=None):
+    """Descriptor of the block's 3x3 convolution (forward) or of its dgrad, with the pre-split weights attached."""
+    N, H, W, _ = x_like.shape
+    if dgrad:
+        d = _desc(g, weight, x_like, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED, out_scale=out_scale, y=y)
+    else:
+        d = _desc(g, weight, x_like, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV, bias, in_scale, in_shift, in_act, out_scale, None, y)
+    need = _C.load().lvae_resblock_conv_workspace(C.byref(d))
+    if need:
+        prepared.attach(d, weight, x_like.device, need, 'lvae_resblock_conv_prepare_entry')
+    return d, need
+
+
+def _rb_gate_ws(e, gate_w, gate_g, device, bwd):
+    """Attach the pre-split copy of the gate weight (direction: forward 64 -> 128, or its dgrad 128 -> 64) to the extension block."""
+    gd = ConvDesc()
+    gd.w, gd.precision = ptr(gate_w), precision
+    if bwd:
+        gd.C1, gd.Cout, gd.w_sk, gd.w_sn, gd.gather = gate_g.Cout, gate_g.Cin, gate_g.s_co, gate_g.s_ci, GATHER_TRANSPOSED
+    else:
+        gd.C1, gd.Cout, gd.w_sk, gd.w_sn, gd.gather = gate_g.Cin, gate_g.Cout, gate_g.s_ci, gate_g.s_co, GATHER_CONV
+    need = _C.load().lvae_resblock_gate_workspace(C.byref(gd))
+    if not need:
+        raise _C.LvaeHipError("fused residual block: the gate convolution must be 1x1, 64 -> 128 channels")
+    prepared.attach(gd, gate_w, device, need, 'lvae_resblock_gate_prepare_entry')
+    e.gate_w, e.gate_w_sk, e.gate_w_sn = gd.w, gd.w_sk, gd.w_sn
+    e.gate_ws, e.gate_ws_bytes, e.gate_ws_ready = gd.workspace, gd.workspace_bytes, gd.workspace_ready
+
+
+def rb_rows(x, weight, g):
+    """Workgroups (= statistics rows) of the fused residual-block kernels for the 3x3 convolution (weight, g) on x, 0 when the shape is
+    not theirs (needs 3x3 / stride 1 / pad 1, 64 -> 64 channels, H*W a divisor of 64, fp32 NHWC x)."""
+    if _ddi is not None or x.dtype != torch.float32 or x.dim() != 4 or g.transposed or g.KH != 3 or g.stride != 1 or g.pad != 1:
+        return 0
+    N, H, W, _ = x.shape   # (no scratch is attached here: asking must not register weights the caller may never run through these kernels)
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV)
+    return int(_C.load().lvae_resblock_conv_rows(C.byref(d)))
+
+
+# Which residual blocks take the fused launches (measured per level at batch 256, tools/rb_bench.py: forward old -> fused 41 -> 31 us at
+# 8x8, 33 -> 26 at 4x4, 22 -> 27 at 2x2, where the position-major kernels skip the taps outside the image; backward 60 -> 43, 46 -> 33,
+# 37 -> 33): forward from 16 pixels per image up, backward everywhere the kernels exist. LVAE_RB_FWD_MIN_HW / LVAE_RB_BWD_MIN_HW
+# (profiling only) move the thresholds; 0 pixels = never.
+import os as _os
+_RB_FWD_MIN_HW = int(_os.environ.get('LVAE_RB_FWD_MIN_HW', '16'))
+_RB_BWD_MIN_HW = int(_os.environ.get('LVAE_RB_BWD_MIN_HW', '1'))
+
+
+def rb_policy(x, weight, g):
+    """(fused forward?, fused backward?) for the residual block whose 3x3 convolutions look like (weight, g) on input x."""
+    if rb_rows(x, weight, g) <= 0:
+        return False, False
+    hw = x.shape[1] * x.shape[2]
+    return (_RB_FWD_MIN_HW > 0 and hw >= _RB_FWD_MIN_HW), (_RB_BWD_MIN_HW > 0 and hw >= _RB_BWD_MIN_HW)
+
+
+def _rb_in_bn(d, in_bn, x):
+    """Training-mode BatchNorm of the convolution input from partial sums: folded into the prologue when the producer stored its pivot,
+    by lvae_bn_finalize_parts_f32 otherwise. Returns (coef 4-tuple, keep-alive)."""
+    sp, pivot, bn = in_bn
+    N, H, W, C1 = x.shape
+    M = N * H * W
+    if sp.has_pivot:
+        coef = torch.empty((4, C1), dtype=torch.float32, device=x.device)
+        fold = BnFold(ptr(sp.buf), sp.rows, M, ptr(bn.weight), ptr(bn.bias), bn.eps, bn.momentum, ptr(bn.running_mean),
+                      ptr(bn.running_var), ptr(coef))
+        d.in_fold = C.addressof(fold)
+        return (coef[0], coef[1], coef[2], coef[3]), fold
+    coef = bn_finalize_parts(sp.rows_view(), M, pivot, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+    d.in_scale, d.in_shift = ptr(coef[0]), ptr(coef[1])
+    return coef, None
+
+
+def rb_weight_ranges(x_like, weight, g, dgrad, gate=None, gate_bwd=False):
+    """[(device pointer, bytes)] of the pre-split weights a later fused launch will stream: the 3x3 convolution (weight, g) in the given
+    direction and optionally the gate (gate = (gate_w, gate_g)). For the `prefetch` argument of the launch that runs just before it."""
+    d, need = _rb_desc(x_like, weight, g, dgrad)
+    out = [(int(d.workspace), int(need))] if need else []
+    if gate is not None:
+        e = RbExt()
+        _rb_gate_ws(e, gate[0], gate[1], x_like.device, gate_bwd)
+        out.append((int(e.gate_ws), int(e.gate_ws_bytes)))
+    return out
+
+
+def _rb_prefetch(e, prefetch):
+    for i, (p, n) in enumerate((prefetch or [])[:2]):
+        e.pf_ptr[i], e.pf_bytes[i] = p, n
+
+
+def rb_conv(x, weight, g, bias, in_act, out_scale, in_bn=None, coef=None, stats_pivot=None, prefetch=None):
+    """y = (conv3x3(act(BN(x))) + bias) * out_scale with BatchNorm partials of y around stats_pivot (first half of a residual block).
+    in_bn = (StatParts, pivot, bn) or coef = (scale, shift, ...) given. Returns (y, StatParts | None, coef)."""
+    N, H, W, _ = x.shape
+    y = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=x.device)
+    d, _ = _rb_desc(x, weight, g, False, y, bias, None, None, in_act, out_scale)
+    keep = None
+    if in_bn is not None:
+        coef, keep = _rb_in_bn(d, in_bn, x)
+    else:
+        d.in_scale, d.in_shift = ptr(coef[0]), ptr(coef[1])
+    parts = None
+    if stats_pivot is not None:
+        rows = _C.load().lvae_resblock_conv_rows(C.byref(d))
+        buf = torch.empty((rows + 1, 2, g.Cout), dtype=torch.float32, device=x.device)
+        parts = StatParts(buf, rows, True)
+        d.stats_out, d.stats_pivot = ptr(buf), ptr(stats_pivot)
+    e = RbExt()
+    e.prologue, e.epilogue = _C.RB_PRO_AFFINE, _C.RB_EPI_PLAIN
+    _rb_prefetch(e, prefetch)
+    call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
+    del keep
+    return y, parts, coef
+
+
+def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bias, res, act, in_bn=None, coef=None, stats_pivot=None):
+    """Second half of a gated residual block in one launch: y2 = (conv3x3(act(BN(x))) + bias) * out_scale, ab = conv1x1(y2) + gate_bias,
+    out = act(a) * sigmoid(b) + res, BatchNorm partials of out around stats_pivot. Returns (y2, ab, out, StatParts | None, coef)."""
+    N, H, W, _ = x.shape
+    dev = x.device
+    y = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=dev)
+    ab = torch.empty((N, H, W, gate_g.Cout), dtype=torch.float32, device=dev)
+    out = torch.empty((N, H, W, gate_g.Cout // 2), dtype=torch.float32, device=dev)
+    d, _ = _rb_desc(x, weight, g, False, y, bias, None, None, in_act, out_scale)
+    keep = None
+    if in_bn is not None:
+        coef, keep = _rb_in_bn(d, in_bn, x)
+    else:
+        d.in_scale, d.in_shift = ptr(coef[0]), ptr(coef[1])
+    e = RbExt()
+    e.prologue, e.epilogue = _C.RB_PRO_AFFINE, _C.RB_EPI_GATE
+    _rb_gate_ws(e, gate_w, gate_g, dev, False)
+    e.gate_bias, e.act = ptr(gate_bias), ACT[act]
+    e.res, e.ab, e.out = ptr(res), ptr(ab), ptr(out)
+    parts = None
+    if stats_pivot is not None:
+        rows = _C.load().lvae_resblock_conv_rows(C.byref(d))
+        buf = torch.empty((rows + 1, 2, g.Cout), dtype=torch.float32, device=dev)
+        parts = StatParts(buf, rows, True)
+        e.out_stats, e.out_stats_pivot = ptr(buf), ptr(stats_pivot)
+    call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
+    del keep
+    return y, ab, out, parts, coef
+
+
+def _rb_bn_bwd(d, bn_bwd, dx):
+    """BatchNorm-backward sums of the dgrad result in the epilogue: bn_bwd = (x, coefficient block row 0, act). Returns the partial rows."""
+    xb, coef0, act = bn_bwd
+    rows = _C.load().lvae_resblock_conv_rows(C.byref(d))
+    parts = torch.empty((rows, 2, dx.shape[3]), dtype=torch.float32, device=dx.device)
+    d.stats_out, d.stats_pivot, d.stats_x = ptr(parts), ptr(coef0), ptr(xb)
+    d.stats_mode, d.stats_act = 1, ACT[act]
+    return parts
+
+
+def rb_gate_dgrad(dout, ab, gate_w, gate_g, act, drop, weight, g, bn_bwd, prefetch=None):
+    """Backward of rb_conv_gate up to the block's second BatchNorm in one launch: dab = gate'(dout, ab), dy2 = (dab . Wg^T) * drop,
+    dh2 = dgrad3x3(dy2) with the BatchNorm-backward sums of bn_bwd = (y1, coef block row 0, act). Returns (dab, dy2, dh2, parts)."""
+    N, H, W, Cn = dout.shape
+    dev = dout.device
+    dab = torch.empty_like(ab)
+    dy2 = torch.empty((N, H, W, Cn), dtype=torch.float32, device=dev)
+    dh = torch.empty((N, H, W, g.Cin), dtype=torch.float32, device=dev)
+    d, _ = _rb_desc(dout, weight, g, True, dh)
+    e = RbExt()
+    e.prologue, e.epilogue = _C.RB_PRO_GATE_BWD, _C.RB_EPI_PLAIN
+    _rb_gate_ws(e, gate_w, gate_g, dev, True)
+    e.act = ACT[act]
+    e.dout, e.ab_in, e.dab, e.pro_drop, e.xt_out = ptr(dout), ptr(ab), ptr(dab), ptr(drop), ptr(dy2)
+    parts = _rb_bn_bwd(d, bn_bwd, dh)
+    _rb_prefetch(e, prefetch)
+    call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
+    return dab, dy2, dh, parts
+
+
+def rb_apply_dgrad(parts_in, dh_in, x_bn, coef0, act, dgamma, dbeta, drop, weight, g, bn_bwd):
+    """BatchNorm backward (training mode; parts_in = the sums the producer of dh_in left) + Dropout2d mask + dgrad of the block's first
+    convolution in one launch: dy1 = BN'(dh_in; x_bn) * drop, dh1 = dgrad3x3(dy1) with the sums of bn_bwd = (x, coef block row 0, act).
+    coef0: row 0 of the (4, C) coefficient block of the BatchNorm being differentiated. Returns (dy1, dh1, parts)."""
+    N, H, W, Cn = dh_in.shape
+    dev = dh_in.device
+    dy1 = torch.empty((N, H, W, Cn), dtype=torch.float32, device=dev)
+    dh = torch.empty((N, H, W, g.Cin), dtype=torch.float32, device=dev)
+    d, _ = _rb_desc(dh_in, weight, g, True, dh)
+    e = RbExt()
+    e.prologue, e.epilogue = _C.RB_PRO_BN_APPLY, _C.RB_EPI_PLAIN
+    e.bwd_parts, e.bwd_rows, e.bwd_act, e.bwd_M = ptr(parts_in), parts_in.shape[0], ACT[act], N * H * W
+    e.bwd_coef, e.bwd_x, e.dgamma, e.dbeta, e.pro_drop, e.xt_out = ptr(coef0), ptr(x_bn), ptr(dgamma), ptr(dbeta), ptr(drop), ptr(dy1)
+    parts = _rb_bn_bwd(d, bn_bwd, dh)
+    call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
+    return dy1, dh, parts
 
 
 def bn_coef_block(scale, shift, mean, rstd):

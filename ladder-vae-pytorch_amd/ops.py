@@ -172,7 +172,14 @@ class ResBlockFn(Function):
         parts, pivot_in = blk.__dict__.pop('_in_parts', None) or (None, None)
         # compute_dtype bf16: conv outputs and gate pre-activations of the block (and, in backward, their gradients) live in bf16 where
         # every kernel involved has that form; the block's input / output (the residual stream) stay fp32
-        s16 = (blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
+        # low-resolution levels (whole images per workgroup): two fused launches per direction (csrc/resblock_img.hip)
+        full = (training and blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
+                blk.conv1.bias is not None and blk.conv2.bias is not None and blk.bn1.running_mean is not None and
+                blk.bn2.running_mean is not None and x.dtype == torch.float32)
+        rb_fwd, rb_bwd = K.rb_policy(x, blk.conv1.weight, blk.conv1.geom()) if full else (False, False)
+        if rb_fwd:
+            return ResBlockFn._forward_fused(ctx, x, blk, m1, m2, parts, pivot_in, rb_bwd)
+        s16 = (not rb_bwd and blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
                (training or not torch.is_grad_enabled()) and K.resblock_bf16_storage(x, blk.conv1.weight, blk.conv1.geom()))
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
@@ -219,7 +226,36 @@ class ResBlockFn(Function):
             out = K.add(y2, x)
         ctx.blk, ctx.training, ctx.s16 = blk, training, s16
         (x0, sc1, sh1, mean1, rstd1), (y1, sc2, sh2, mean2, rstd2) = st
+        ctx.rb_bwd = bool(rb_bwd and ab is not None and K.bn_coef_block(sc1, sh1, mean1, rstd1) and K.bn_coef_block(sc2, sh2, mean2, rstd2))
         ctx.save_for_backward(x0, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2)
+        return out
+
+    @staticmethod
+    def _forward_fused(ctx, x, blk, m1, m2, parts, pivot_in, rb_bwd):
+        """conv1 (+ BatchNorm-2 partial sums) and conv2 + gate + residual (+ the next block's BatchNorm partial sums): two launches."""
+        act = blk.act
+        bn1, bn2, cv1, cv2, gate = blk.bn1, blk.bn2, blk.conv1, blk.conv2, blk.gate
+        in_bn = coef1 = None
+        if parts is not None and parts.has_pivot:
+            in_bn = (parts, pivot_in, bn1)
+        elif parts is not None:
+            N, H, W, _ = x.shape
+            coef1 = K.bn_finalize_parts(parts.rows_view(), N * H * W, pivot_in, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                                        bn1.eps, bn1.momentum)
+        else:
+            coef1 = K.bn_stats(x, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
+        nxt = K.rb_weight_ranges(x, cv2.weight, cv2.geom(), False, gate=(gate.weight, gate.geom()))   # what the second launch will stream
+        y1, parts2, coef1 = K.rb_conv(x, cv1.weight, cv1.geom(), cv1.bias, act, m1, in_bn=in_bn, coef=coef1, stats_pivot=bn2.running_mean,
+                                      prefetch=nxt)
+        blk.__dict__['_out_parts'] = None
+        pivot = coef1[2].detach() if _GATE_STATS else None   # this block's own batch mean: inside the data range of the residual stream
+        y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, cv2.weight, cv2.geom(), cv2.bias, act, m2, gate.weight, gate.geom(), gate.bias, x, act,
+                                                    in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot)
+        if oparts is not None:
+            blk.__dict__['_out_parts'] = (oparts, pivot)
+        ctx.blk, ctx.training, ctx.s16 = blk, True, False
+        ctx.rb_bwd = bool(rb_bwd and K.bn_coef_block(*coef1) and K.bn_coef_block(*coef2))
+        ctx.save_for_backward(x, y1, y2, ab, coef1[0], coef1[1], coef1[2], coef1[3], coef2[0], coef2[1], coef2[2], coef2[3], m1, m2)
         return out
 
     @staticmethod
@@ -230,6 +266,20 @@ class ResBlockFn(Function):
         dout = _c(dout)
         hw = (x.shape[1], x.shape[2])
         s16 = ctx.s16   # bf16-stored block internals: every launch below then has to take the bf16-storage kernel (it raises otherwise)
+        if ctx.rb_bwd:
+            # low-resolution levels: gate backward + dgrad conv2, then BatchNorm-2 backward + dgrad conv1, then the BatchNorm-1 apply
+            gate, w2, w1, bn2, bn1 = blk.gate, blk.conv2.weight, blk.conv1.weight, blk.bn2, blk.bn1
+            gw = gate.weight
+            dab, dy2, dh2, parts2 = K.rb_gate_dgrad(dout, ab, gw, gate.geom(), act, m2, w2, blk.conv2.geom(), bn_bwd=(y1, sc2, act),
+                                                    prefetch=K.rb_weight_ranges(dout, w1, blk.conv1.geom(), True))
+            if gw.requires_grad:
+                wgrad(y2, dab, gw, gate.geom(), grad_buf(gw), grad_buf(gate.bias))
+            wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2, in_act=act)
+            dy1, dh1, parts1 = K.rb_apply_dgrad(parts2, dh2, y1, sc2, act, grad_buf(bn2.weight), grad_buf(bn2.bias), m1, w1, blk.conv1.geom(),
+                                                bn_bwd=(x, sc1, act))
+            wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
+            dx = K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias), add=dout)
+            return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
         if blk.gate is not None:
             gw = blk.gate.weight
             dy2 = None

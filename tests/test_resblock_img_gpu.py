@@ -1,0 +1,155 @@
+"""Fused residual-block kernels of the low-resolution levels (csrc/resblock_img.hip, lvae_resblock_conv_f32) against a plain torch
+float64 statement of the reference's gated 'bacdbacd' block (lib/nn.py:78-99, 118-126) and its autograd: forward (two launches),
+backward (two launches + the existing BatchNorm-1 apply), all intermediate tensors, statistics and parameter-gradient inputs."""
+import math
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    import lvae_amd  # noqa: F401
+    from lvae_amd import kernels
+    return kernels
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).cpu().double()
+
+
+def packed_weight(w):
+    return w.float().permute(2, 3, 1, 0).contiguous().cuda().permute(3, 2, 0, 1)
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_block(N, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    C = 64
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    p = types.SimpleNamespace()
+    p.x = r(N, C, H, W).requires_grad_(True)
+    p.w1 = (r(C, C, 3, 3) / (3 * math.sqrt(C))).requires_grad_(True)
+    p.w2 = (r(C, C, 3, 3) / (3 * math.sqrt(C))).requires_grad_(True)
+    p.b1, p.b2 = (0.1 * r(C)).requires_grad_(True), (0.1 * r(C)).requires_grad_(True)
+    p.wg = (r(2 * C, C, 1, 1) / math.sqrt(C)).requires_grad_(True)
+    p.bg = (0.1 * r(2 * C)).requires_grad_(True)
+    p.g1, p.g2 = (1 + 0.1 * r(C)).requires_grad_(True), (1 + 0.1 * r(C)).requires_grad_(True)
+    p.be1, p.be2 = (0.1 * r(C)).requires_grad_(True), (0.1 * r(C)).requires_grad_(True)
+    p.m1 = (torch.rand(N, C, generator=g) < 0.8).double() / 0.8
+    p.m2 = (torch.rand(N, C, generator=g) < 0.8).double() / 0.8
+    p.dout = r(N, C, H, W)
+    return p
+
+
+def reference(p):
+    """float64 torch statement of the block and of everything the kernels hand to each other"""
+    o = types.SimpleNamespace()
+    bn = lambda t, ga, be: F.batch_norm(t, None, None, ga, be, True, 0.1, 1e-5)
+    o.h1 = F.elu(bn(p.x, p.g1, p.be1))
+    o.y1 = (F.conv2d(o.h1, p.w1, p.b1, padding=1) * p.m1[:, :, None, None])
+    o.h2 = F.elu(bn(o.y1, p.g2, p.be2))
+    o.y2 = (F.conv2d(o.h2, p.w2, p.b2, padding=1) * p.m2[:, :, None, None])
+    o.ab = F.conv2d(o.y2, p.wg, p.bg)
+    a, b = o.ab.chunk(2, 1)
+    o.out = F.elu(a) * torch.sigmoid(b) + p.x
+    for t in (o.h1, o.y1, o.h2, o.y2, o.ab):
+        t.retain_grad()
+    o.out.backward(p.dout)
+    return o
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(256, 4, 4), (64, 8, 8), (37, 2, 2), (7, 8, 8), (130, 4, 4), (1, 2, 2), (300, 8, 8)])
+def test_fused_block_forward_and_backward(K, shape, prec):
+    N, H, W = shape
+    C = 64
+    p = make_block(N, H, W, 7 * N + H)
+    o = reference(p)
+    tol = 1.0 if prec == 'f32' else 4000.0   # bf16 operands: 2^-9 relative per product instead of 2^-24
+    K.set_precision(prec)
+    try:
+        dev = 'cuda'
+        f = lambda t: t.detach().float().to(dev)
+        x = nhwc(p.x.detach())
+        w1, w2, wg = packed_weight(p.w1.detach()), packed_weight(p.w2.detach()), packed_weight(p.wg.detach())
+        ge1, ge2, geg = K.ConvGeom(w1, 1, 1), K.ConvGeom(w2, 1, 1), K.ConvGeom(wg, 1, 0)
+        assert K.rb_rows(x, w1, ge1) > 0
+        mk_bn = lambda ga, be: types.SimpleNamespace(weight=f(ga), bias=f(be), running_mean=torch.zeros(C, device=dev),
+                                                     running_var=torch.ones(C, device=dev), eps=1e-5, momentum=0.1)
+        bn1, bn2 = mk_bn(p.g1, p.be1), mk_bn(p.g2, p.be2)
+        m1, m2 = p.m1.float().to(dev), p.m2.float().to(dev)
+        # ---- forward: BN1 statistics by the stand-alone kernel (first block of a chain), then the two fused launches
+        coef1 = K.bn_stats(x, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
+        y1, parts2, _ = K.rb_conv(x, w1, ge1, f(p.b1), 'elu', m1, coef=coef1, stats_pivot=bn2.running_mean)
+        pivot = coef1[2]
+        y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, w2, ge2, f(p.b2), 'elu', m2, wg, geg, f(p.bg), x, 'elu',
+                                                    in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot)
+        torch.cuda.synchronize()
+        assert rel(nchw(y1), o.y1.detach()) < 2e-6 * tol
+        assert rel(nchw(y2), o.y2.detach()) < 3e-6 * tol
+        assert rel(nchw(ab), o.ab.detach()) < 3e-6 * tol
+        assert rel(nchw(out), o.out.detach()) < 3e-6 * tol
+        # folded BatchNorm-2 finalize: coefficients and running statistics as nn.BatchNorm2d would leave them
+        y1r = o.y1.detach()
+        mean2, var2 = y1r.mean((0, 2, 3)), y1r.var((0, 2, 3), unbiased=False)
+        stol = dict(rtol=1e-5 * tol, atol=1e-5 * tol)
+        torch.testing.assert_close(coef2[2].cpu().double(), mean2, **stol)
+        torch.testing.assert_close(coef2[3].cpu().double(), 1 / torch.sqrt(var2 + 1e-5), **stol)
+        M = N * H * W
+        torch.testing.assert_close(bn2.running_mean.cpu().double(), 0.1 * mean2, **stol)
+        torch.testing.assert_close(bn2.running_var.cpu().double(), 0.9 + 0.1 * var2 * M / max(M - 1, 1), **stol)
+        # statistics of `out` for the next block: partial rows around the pivot, and the pivot behind them
+        s = oparts.rows_view().double().sum(0).cpu()
+        dl = o.out.detach() - pivot.cpu().double().view(1, -1, 1, 1)
+        torch.testing.assert_close(s[0], dl.sum((0, 2, 3)), rtol=1e-4 * tol, atol=1e-3 * tol)
+        torch.testing.assert_close(s[1], (dl * dl).sum((0, 2, 3)), rtol=1e-4 * tol, atol=1e-3 * tol)
+        assert torch.equal(oparts.buf[oparts.rows, 0], pivot)
+        # ---- backward
+        dout = nhwc(p.dout)
+        assert K.bn_coef_block(*coef2) and K.bn_coef_block(*coef1)
+        dab, dy2, dh2, bparts2 = K.rb_gate_dgrad(dout, ab, wg, geg, 'elu', m2, w2, ge2, bn_bwd=(y1, coef2[0], 'elu'))
+        dg2, db2 = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)   # accumulated into
+        dy1, dh1, bparts1 = K.rb_apply_dgrad(bparts2, dh2, y1, coef2[0], 'elu', dg2, db2, m1, w1, ge1, bn_bwd=(x, coef1[0], 'elu'))
+        dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx = K.affine_act_bwd_parts(bparts1, dh1, x, coef1[0], coef1[1], 'elu', coef1[2], coef1[3], dg1, db1, add=dout)
+        torch.cuda.synchronize()
+        btol = tol * 3
+        assert rel(nchw(dab), o.ab.grad) < 2e-6 * btol
+        # gradient w.r.t. conv2's output (before the Dropout2d mask) = y2.grad * m2
+        assert rel(nchw(dy2), o.y2.grad * p.m2[:, :, None, None]) < 3e-6 * btol
+        assert rel(nchw(dh2), o.h2.grad) < 4e-6 * btol
+        assert rel(nchw(dy1), o.y1.grad * p.m1[:, :, None, None]) < 6e-6 * btol
+        assert rel(nchw(dh1), o.h1.grad) < 8e-6 * btol
+        assert rel(nchw(dx), p.x.grad) < 1e-5 * btol
+        gt = dict(rtol=2e-4 * btol, atol=2e-4 * btol)
+        torch.testing.assert_close(dg2.cpu().double() - 0.5, p.g2.grad, **gt)
+        torch.testing.assert_close(db2.cpu().double() + 0.25, p.be2.grad, **gt)
+        torch.testing.assert_close(dg1.cpu().double(), p.g1.grad, **gt)
+        torch.testing.assert_close(db1.cpu().double(), p.be1.grad, **gt)
+    finally:
+        K.set_precision('f32')
+
+
+def test_fused_block_shape_gate(K):
+    """lvae_resblock_conv_rows: only 64 -> 64 channel 3x3 / stride 1 / pad 1 layers whose images divide a 64-pixel tile."""
+    mk = lambda co, ci, k: packed_weight(torch.randn(co, ci, k, k))
+    w = mk(64, 64, 3)
+    ge = K.ConvGeom(w, 1, 1)
+    for hw, want in (((8, 8), True), ((4, 4), True), ((2, 2), True), ((16, 16), False), ((6, 6), False), ((4, 8), True)):
+        x = torch.zeros(5, hw[0], hw[1], 64, device='cuda')
+        assert (K.rb_rows(x, w, ge) > 0) == want, hw
+    w32 = mk(64, 32, 3)
+    assert K.rb_rows(torch.zeros(5, 4, 4, 32, device='cuda'), w32, K.ConvGeom(w32, 1, 1)) == 0
+    assert K.rb_rows(torch.zeros(5, 4, 4, 64, device='cuda'), w, K.ConvGeom(w, 2, 1)) == 0
