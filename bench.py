@@ -7,12 +7,14 @@ rank processes its own 256-image shard; `value` = images of all ranks / max-over
 
 Extra objects in the JSON line:
   roofline     — the dominant kernel (the convolution shape with the largest total time in an instrumented eager step, timed
-                 with HIP events on the launch stream; not part of `value`): `achieved` = ALGORITHMIC direct-convolution FLOPs per
-                 launch / average launch time against the fp32-MFMA peak, as the contract asks; because that kernel is Winograd
-                 F(2x2,3x3) it ISSUES only 16/36 of those FLOPs, so `mfma_issued_frac` (what the matrix pipe really does) and
-                 `frac_of_winograd_floor` are given next to it, and `step` holds the whole-step fractions of both roofs.
-  bf16_shard   — the same step with compute_dtype = 'bf16' (BASELINE configs[3] per-GPU shard: bf16 matrix-core operands in the
-                 3x3 convolutions that have a bf16 kernel, fp32 storage / accumulation / statistics), with its HBM roofline.
+                 with HIP events on the launch stream; not part of `value`): `frac` = matrix FLOPs the kernel ISSUES per launch (Winograd
+                 F(2x2,3x3): 16/36 of the direct multiplies, each as six bf16-piece products) / average launch time / the dense peak of
+                 the unit that issues them (bf16 MFMA); `effective_tflops` keeps the algorithmic direct-convolution rate, `step` holds the
+                 whole-step fractions of both roofs and the PMC-measured traffic.
+  bf16_shard   — the same step with compute_dtype = 'bf16' (BASELINE configs[3] per-GPU shard: bf16 matrix-core operands, bf16 storage
+                 of the residual-block internals, fp32 accumulation / statistics / residual stream), with its HBM roofline.
+  other_configs — BASELINE configs[1] (static-MNIST 12-layer, bf16, batch 256) and configs[4]'s per-GPU shard (64x64 20-layer, bf16,
+                 batch 128) through the same TrainStep: 5 untimed + 10 timed steps each, ms/step, images/s and the step's HBM fraction.
   cpu_baseline — the CPU oracle (oracle/lvae_ref.py, a port of the reference) timed on this box's host cores on a bounded
                  sample (rank 0, N=1 only): BASELINE configs[0] at batch 64 and CIFAR-15 at batch 32, 2 warm-up + 5 timed steps.
 """
@@ -29,7 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import lvae_amd  # noqa: E402,F401
-from lvae_amd.configs import CIFAR15, MNIST3, synthetic_images  # noqa: E402  (the dicts the full-size parity tests build their models from)
+from lvae_amd.configs import CELEBA20, CIFAR15, MNIST3, MNIST12, synthetic_images  # noqa: E402  (the dicts the full-size parity tests build their models from)
 
 PEAK_MFMA_F32 = 157.3   # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0       # GB/s, MI355X_MICROARCH.md (spec; 6.3 TB/s is what a streaming copy achieves)
@@ -201,6 +203,50 @@ def cpu_baseline():
             'cfg1_mnist3_b64_images_per_s': v1}
 
 
+# BASELINE configs[1] and configs[4] (per-GPU shard): (key, constructor dict, images per GPU, algorithmic FLOPs and bf16 bytes per image
+# of SURVEY.md §8d / BASELINE.md §4)
+OTHER_CONFIGS = (
+    ('cfg2_mnist12_bf16_b256', 'BASELINE configs[1]: static-MNIST 12-layer LVAE, Bernoulli likelihood, bf16, batch 256', MNIST12, 256, 8.337e9, 46.73e6),
+    ('cfg5_celeba20_bf16_b128', 'BASELINE configs[4] per-GPU shard: 64x64 20-layer LVAE, DMoL-10, bf16, batch 128 (1024 over 8 GPUs)', CELEBA20, 128, 42.472e9, 233.10e6),
+)
+
+
+def time_other_config(desc, cfg, batch, f_alg_img, b_alg_img, dev, steps=10, warmup=5):
+    """One of the other BASELINE configurations through the same TrainStep (hipGraph) as the headline: `warmup` untimed + `steps` timed
+    steps on a ring of 4 resident synthetic batches, compute_dtype bf16. The model and its graph are dropped afterwards."""
+    import gc
+    from lvae_amd import kernels as K
+    from lvae_amd.engine import TrainStep
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import PhiloxNoise
+    from lvae_amd.optim import Adamax
+    torch.manual_seed(42)
+    model = LadderVAE(**cfg).to(dev)
+    model.train()
+    model.compute_dtype = 'bf16'
+    model.noise = PhiloxNoise(seed=42, rank=0)
+    model.pack()
+    step = TrainStep(model, Adamax(model, lr=3e-4), use_graph=True)
+    gen = torch.Generator().manual_seed(1234)
+    ring = [synthetic_images(cfg, batch, gen).to(dev) for _ in range(4)]
+    for i in range(max(warmup, 3)):
+        step(ring[i % 4])
+    dt, out = time_steps(step, ring, steps, 1, dev)
+    s = dt / steps
+    rec = {'config': desc, 'value': batch / s, 'unit': 'images/s', 'ms_per_step': s * 1e3, 'steps': steps, 'warmup': warmup, 'dtype': 'bf16',
+           'batch_per_gpu': batch, 'hip_graph': step.use_graph, 'neg_elbo': -float(out['elbo']),
+           'step': {'algorithmic_gb_per_s': b_alg_img * batch / s / 1e9, 'hbm_frac': b_alg_img * batch / s / 1e9 / PEAK_HBM,
+                    'hbm_floor_ms': b_alg_img * batch / (PEAK_HBM * 1e9) * 1e3, 'algorithmic_tflops': f_alg_img * batch / s / 1e12,
+                    'bf16_mfma_frac': f_alg_img * batch / s / 1e12 / PEAK_MFMA_BF16,
+                    'note': 'algorithmic bytes = BASELINE.md §4 (2 B per activation element, fwd + dgrad + wgrad of every convolution)'}}
+    del step, model, ring, out
+    gc.collect()
+    K.prepared.evict_dead()
+    K.set_precision('f32')
+    torch.cuda.empty_cache()
+    return rec
+
+
 def time_steps(step, ring, n, world, dev):
     torch.cuda.synchronize()
     if world > 1:
@@ -333,6 +379,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-bf16-line', action='store_true', help='skip the nested bf16_shard measurement of the default fp32 run')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the nested measurements of BASELINE configs[1] and configs[4] (per-GPU shard)')
     ap.add_argument('--launch-check', action='store_true',
                     help='rendezvous rehearsal without a GPU: every rank joins the process group (use --backend gloo), all-reduces one host '
                          'scalar and rank 0 prints a JSON line; exercises the self-launch path of --gpus N (tests/test_dist_cpu.py)')
@@ -468,6 +515,11 @@ def main():
             'value': args.batch / s16, 'unit': 'images/s', 'ms_per_step': s16 * 1e3, 'steps': n16, 'dtype': 'bf16',
             'neg_elbo': -float(out16['elbo']), 'roofline': r16}
         log('bf16 shard: %.2f ms/step' % (s16 * 1e3))
+    if rank == 0 and world == 1 and args.dtype == 'f32' and not args.no_other_configs:
+        line['other_configs'] = {}
+        for key, desc, cfg, batch, f_img, b_img in OTHER_CONFIGS:
+            line['other_configs'][key] = time_other_config(desc, cfg, batch, f_img, b_img, dev)
+            log('%s: %.2f ms/step' % (key, line['other_configs'][key]['ms_per_step']))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline on %d host cores ...' % host_cores())
         line['cpu_baseline'] = cpu_baseline()

@@ -18,10 +18,9 @@
  *    variants are compile-time constants (csrc/lvae_common.h tune(); a -DLVAE_TUNING_ENV build, used by tools/ only, can sweep them
  *    through LVAE_* variables). Variants that were measured slower in round 2 (256-pixel Winograd workgroups, the persistent bf16 3x3
  *    kernel, the six-product weight gradient) are no longer compiled; phase-skip switches exist only in -DLVAE_PHASE_DEBUG builds.
- *  - collectives are NOT part of this library: the data-parallel exchange is torch.distributed (RCCL) on device buffers the
- *    caller owns (ladder-vae-pytorch_amd/dist.py). SURVEY.md §8(b) sketched lvae_allreduce_{init,enqueue,wait,destroy}; they
- *    would only re-wrap ncclAllReduce on a side stream, which torch.distributed already is on this platform, so the boundary
- *    stops at "gradients complete in one flat device buffer" (lvae_adamax_step_f32 takes the 1/world scale).
+ *  - the data-parallel gradient exchange is part of the library too (lvae_allreduce_*, at the end of this file): a private RCCL communicator
+ *    whose ncclAllReduce runs on a side stream forked off / joined to the launch stream by the library; librccl is resolved at run time
+ *    from the path the caller passes (this library has no link-time dependency on it).
  */
 #ifndef LVAE_HIP_H
 #define LVAE_HIP_H
@@ -503,6 +502,28 @@ int lvae_rng_fill_f32(float* out, int64_t n, int32_t kind, float lo, float hi, u
 int lvae_counter_advance(uint64_t* counter, uint64_t by, void* stream);
 /* out[0:n] = value (16-byte aligned out). replaces: optimizer.zero_grad() of boilr's training loop on the flat gradient arena. */
 int lvae_fill_f32(float* out, int64_t n, float value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step (the reference itself is single-process): SUM all-reduce of slices of
+ * the flat fp32 gradient arena over the ranks of one node through a communicator of our own on librccl (RCCL over xGMI), each bucket on a
+ * SIDE stream so that it overlaps the backward kernels still being issued. All calls enqueue work and return; nothing synchronises.
+ * Inside a hipGraph capture the fork / join become graph edges and RCCL's kernels graph nodes.
+ *   lvae_allreduce_unique_id  rank 0 only: a 128-byte communicator id, to be handed to every rank by the caller (e.g. an eager broadcast)
+ *   lvae_allreduce_init       every rank (collective: ncclCommInitRank), with this rank's GPU current; *handle owns the communicator and
+ *                             two events
+ *   lvae_allreduce_enqueue    buf[0:n] = sum over ranks, enqueued on side_stream behind everything issued on launch_stream so far.
+ *                             scratch (n floats) non-NULL: out of place into scratch + copy back — for one-rank rehearsals, where the
+ *                             in-place form enqueues nothing; NULL: in place
+ *   lvae_allreduce_wait       launch_stream waits for everything enqueued on side_stream so far (call before the optimizer step)
+ *   lvae_allreduce_destroy    releases the communicator and the events (NULL is a no-op)
+ * librccl_path: the librccl.so of the process (torch ships one: <torch>/lib/librccl.so). Errors: LVAE_E*, a hipError_t, or 1000 + the
+ * ncclResult_t; lvae_last_error() has the text.
+ * ---------------------------------------------------------------------------------------------------------- */
+int lvae_allreduce_unique_id(const char* librccl_path, void* id128);
+int lvae_allreduce_init(const char* librccl_path, const void* id128, int32_t world, int32_t rank, void** handle);
+int lvae_allreduce_enqueue(void* handle, float* buf, int64_t n, float* scratch, void* launch_stream, void* side_stream);
+int lvae_allreduce_wait(void* handle, void* launch_stream, void* side_stream);
+int lvae_allreduce_destroy(void* handle);
 
 #ifdef __cplusplus
 }

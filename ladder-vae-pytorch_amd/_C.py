@@ -134,6 +134,11 @@ SIGNATURES = {
     'lvae_rng_fill_f32': (C.c_int, [_P, _L, _I, _F, _F, _U, _P, _U, _P]),
     'lvae_counter_advance': (C.c_int, [_P, _U, _P]),
     'lvae_fill_f32': (C.c_int, [_P, _L, _F, _P]),
+    'lvae_allreduce_unique_id': (C.c_int, [C.c_char_p, _P]),
+    'lvae_allreduce_init': (C.c_int, [C.c_char_p, _P, _I, _I, C.POINTER(C.c_void_p)]),
+    'lvae_allreduce_enqueue': (C.c_int, [_P, _P, _L, _P, _P, _P]),
+    'lvae_allreduce_wait': (C.c_int, [_P, _P, _P]),
+    'lvae_allreduce_destroy': (C.c_int, [_P]),
 }
 
 _lib = None
@@ -161,15 +166,22 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t):
-    """device pointer of a tensor (None -> NULL). Refuses CPU tensors: the HIP path never runs on host memory."""
+def ptr(t, dtypes=(torch.float32, torch.int64, torch.uint8)):
+    """device pointer of a tensor (None -> NULL). Refuses CPU tensors: the HIP path never runs on host memory. fp32 (and the integer
+    types of counters / scratch) only: an entry point that has a storage-type argument for the tensor takes it through ptr_dt()."""
     if t is None:
         return None
     if not t.is_cuda:
         raise LvaeHipError("lvae_hip kernels need CUDA/HIP tensors; got a %s tensor (no CPU fallback exists)" % t.device)
-    if t.dtype not in (torch.float32, torch.bfloat16, torch.int64, torch.uint8):
-        raise LvaeHipError("unexpected dtype %s" % t.dtype)
+    if t.dtype not in dtypes:
+        raise LvaeHipError("unexpected dtype %s for this entry point (it has no storage-type argument for this tensor)" % t.dtype)
     return t.data_ptr()
+
+
+def ptr_dt(t):
+    """device pointer of an activation tensor whose element type (fp32 | bf16) the callee is TOLD through a dtype field / mask of the
+    same call (lvae_conv_desc.x_dtype / y_dtype / stats_x_dtype, the `dtypes` mask of lvae_affine_act_bwd_parts_f32)."""
+    return ptr(t, (torch.float32, torch.bfloat16))
 
 
 def check(rc, name):

@@ -409,9 +409,13 @@ size_t conv1x1_gate_bwd_fused_workspace(const lvae_conv_desc* d);
 extern "C" int32_t lvae_resblock_bf16_storage(const lvae_conv_desc* d) {
   if (d == nullptr || d->precision != LVAE_PREC_BF16 || d->C1 != 64 || d->C2 != 0 || d->Cout != 64 || d->gather != LVAE_GATHER_CONV) return 0;
   if (lvae_conv2d_variant(d) != LVAE_VARIANT_BF16_DIRECT) return 0;
+  // the block's BatchNorm statistics / BatchNorm-backward sums must come out of the convolutions' own epilogues: the stand-alone
+  // statistics kernels have no bf16-storage form
+  if (lvae_conv2d_stats_rows(d) <= 0) return 0;
   lvae_conv_desc t = *d;  // dgrad view of the same layer (same shape; only the gather differs for the kernel choice)
   t.gather = LVAE_GATHER_TRANSPOSED;
   if (lvae_conv2d_variant(&t) != LVAE_VARIANT_BF16_DIRECT) return 0;
+  if (lvae_conv2d_stats_rows(&t) <= 0) return 0;
   if (conv3x3_wgrad_bf16_workspace(d) == 0) return 0;
   lvae_conv_desc g = *d;  // the block's GateLayer2d: 1x1, 64 -> 128 forward; its fused backward is described by the 128 -> 64 dgrad view
   g.KH = g.KW = 1; g.pad = 0; g.Cout = 128; g.in_scale = g.in_shift = nullptr; g.out_scale = nullptr; g.in_act = g.out_act = 0; g.in_fold = nullptr;

@@ -111,6 +111,17 @@ class GradAllReduce:
                 self.comm = rccl.Comm(group)
             except Exception as e:  # noqa: BLE001  (no private communicator: the process group's collectives, never captured)
                 self.comm_error = '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
+            # ncclCommInitRank is a collective and may fail on ONE rank: every rank learns whether ALL have a communicator before any of
+            # them issues a collective on it (a rank without one would otherwise skip calls its peers block in)
+            have = torch.tensor([1.0 if self.comm is not None else 0.0], device=flat_grads.device)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+            if float(have.item()) == 0.0 and self.comm is not None:
+                self.comm.destroy()
+                self.comm, self.comm_error = None, 'another rank has no private communicator'
+        # one-rank rehearsal (LVAE_FORCE_DIST=1): the out-of-place form, so that the captured exchange holds real RCCL / copy nodes
+        self.scratch = None
+        if self.comm is not None and self.world == 1:
+            self.scratch = torch.empty(max(hi - lo for lo, hi, _ in self.buckets), dtype=torch.float32, device=flat_grads.device)
 
     def capture_probe(self):
         """Can a collective on the side stream be captured into a hipGraph here? Captures (and replays once) a throw-away graph holding one
@@ -122,7 +133,7 @@ class GradAllReduce:
         if self.comm is None:
             return False, 'no private RCCL communicator (%s): the process group\'s collectives are not captured' % (self.comm_error or 'not created')
         dev = self.flat.device
-        t = torch.zeros(256, dtype=torch.float32, device=dev)
+        t = torch.ones(256, dtype=torch.float32, device=dev)
         ok, reason = True, ''
         self._all_reduce(t)   # eager first: everything lazy inside the communicator happens before anything is captured
         torch.cuda.synchronize(dev)
@@ -130,23 +141,35 @@ class GradAllReduce:
         try:
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 cur = torch.cuda.current_stream(dev)
-                self.stream.wait_stream(cur)
                 try:
-                    with torch.cuda.stream(self.stream):
-                        self._all_reduce(t)
+                    self.comm.enqueue(t, cur, self.stream, self.scratch)    # the library forks the side stream off the capturing one
                 except Exception as e:  # noqa: BLE001  (join the fork before leaving the capture, then report)
                     ok, reason = False, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
-                cur.wait_stream(self.stream)
-            if ok:
-                g.replay()
+                self.comm.wait(cur, self.stream)
         except Exception as e:  # noqa: BLE001
             ok, reason = False, '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')
-        torch.cuda.synchronize(dev)
-        del g
+        # the graph holds a collective: it is replayed only when EVERY rank captured it (a rank that did not would leave its peers
+        # waiting inside the replay); the vote is an eager collective of the process group
         flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)     # eager: every rank takes the same branch afterwards
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if ok and float(flag.item()) == 0.0:
             ok, reason = False, 'another rank could not capture the collective'
+        if ok:
+            before = float(t[0].item())
+            g.replay()
+            torch.cuda.synchronize(dev)
+            after = float(t[0].item())
+            self.probe_nodes_ran = after == before * self.world   # the replayed SUM multiplied the (already reduced) ones by the world size
+            if self.world == 1 and self.scratch is not None:
+                # one rank: the sum is the identity, so the only evidence that the captured branch holds work is that it wrote the scratch
+                self.scratch[:256].zero_()
+                g.replay()
+                torch.cuda.synchronize(dev)
+                self.probe_nodes_ran = bool((self.scratch[:256] == t).all().item())
+                if not self.probe_nodes_ran:
+                    ok, reason = False, 'the captured exchange replayed without doing any work (empty graph branch)'
+        torch.cuda.synchronize(dev)
+        del g
         return ok, reason
 
     @property
@@ -159,9 +182,15 @@ class GradAllReduce:
 
     def _all_reduce(self, t):
         if self.comm is not None:
-            self.comm.all_reduce_(t)            # on torch's current stream (the side stream when called from _launch_through)
+            self.comm.all_reduce_(t, scratch=self.scratch)   # on torch's current stream, no fork (eager uses)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def close(self):
+        """Release the private communicator (teardown; the object is unusable for GPU exchanges afterwards)."""
+        if self.comm is not None:
+            self.comm.destroy()
+            self.comm = None
 
     def _reduce(self, k):
         lo, hi, _ = self.buckets[k]
@@ -177,13 +206,21 @@ class GradAllReduce:
                 self._reduce(b)
         else:
             cur = torch.cuda.current_stream(self.flat.device)
-            self.stream.wait_stream(cur)           # fork: everything issued so far (this bucket's last gradient kernel included)
             from . import ops
             for st in (ops._side.get('stream') or ()):
                 self.stream.wait_stream(st)        # weight-gradient kernels issued on side streams (async_wgrad) write this bucket too
-            with torch.cuda.stream(self.stream):
+            if self.comm is not None:
                 for b in range(self.next_bucket, k + 1):
-                    self._reduce(b)
+                    lo, hi, _ = self.buckets[b]
+                    # lvae_allreduce_enqueue: fork (everything issued on the launch stream so far, this bucket's last gradient kernel
+                    # included) + ncclAllReduce on the side stream
+                    self.comm.enqueue(self.flat[lo:hi], cur, self.stream, self.scratch)
+                    self.launched.append(b)
+            else:
+                self.stream.wait_stream(cur)
+                with torch.cuda.stream(self.stream):
+                    for b in range(self.next_bucket, k + 1):
+                        self._reduce(b)
         self.next_bucket = k + 1
 
     def segment_done(self, seg):
@@ -201,7 +238,11 @@ class GradAllReduce:
             return
         self._launch_through(len(self.buckets) - 1)
         if self.on_gpu:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self.comm is not None:
+                self.comm.wait(cur, self.stream)   # lvae_allreduce_wait: join
+            else:
+                cur.wait_stream(self.stream)
 
     def run(self):
         """Reduce all buckets after backward; the caller's current stream waits for completion (no host sync)."""

@@ -74,14 +74,15 @@ class TrainStep:
             model.grad_tracker = allreduce   # the model's segment markers report to it during backward
 
     def _fwd_bwd(self, x):
-        self.opt.zero_grad()
-        K.prepared.prepare_all()  # one launch: transformed weights of every Winograd convolution seen so far
-        out = forward_pass(self.model, x, self.beta)
-        if self.allreduce is not None:
-            self.allreduce.begin_step()
-        ops.set_wgrad_stream(self.side)
-        ops.set_wgrad_grouping(self.wgrad_group_rows)
+        done = False
         try:
+            self.opt.zero_grad()
+            K.prepared.prepare_all()  # one launch: transformed weights of every Winograd convolution seen so far
+            out = forward_pass(self.model, x, self.beta)
+            if self.allreduce is not None:
+                self.allreduce.begin_step()
+            ops.set_wgrad_stream(self.side)
+            ops.set_wgrad_grouping(self.wgrad_group_rows)
             if self.side is not None:
                 for st in self.side:
                     st.wait_stream(torch.cuda.current_stream())  # zero_grad happens-before every wgrad accumulate
@@ -90,7 +91,23 @@ class TrainStep:
             ops.join_wgrad_stream()
             if self.overlap:
                 self.allreduce.finish()  # last bucket + join: the gradients are summed over ranks from here on
+            done = True
         finally:
+            if not done:
+                # The pass was abandoned by an exception (possibly inside a hipGraph capture that is being torn down). Nothing more may be
+                # LAUNCHED on its behalf: the queued weight gradients are dropped, not flushed (their inputs belong to the abandoned pass);
+                # the transformed-weight stamps are withdrawn (prepare_all marked the buffers current for a launch that may never have
+                # run); the exchange's bucket cursor is rewound; side streams are joined so that no fork is left dangling. The next
+                # step — eager or a fresh capture — starts from a clean state (tests/test_model_gpu.py raises inside a captured backward).
+                ops.drop_wgrad_group()
+                K.prepared.invalidate()
+                if self.allreduce is not None:
+                    self.allreduce.begin_step()
+                if not torch.cuda.is_current_stream_capturing():
+                    try:
+                        ops.join_wgrad_stream()
+                    except RuntimeError:
+                        pass
             ops.set_wgrad_grouping(None)
             ops.set_wgrad_stream(None)
         return {k: out[k].detach() for k in ('loss', 'elbo', 'recons', 'kl', 'l2', 'kl_avg_layerwise')}
@@ -111,10 +128,16 @@ class TrainStep:
         # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures.
         # (Whether the exchange CAN be captured was settled by GradAllReduce.capture_probe() in __init__: a refusal inside this capture
         # would leave a half-captured training step behind, and unwinding that is not safe.)
-        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
-            self.static_out = self._fwd_bwd(self.static_x)
-            if fused:
-                self.opt.step()
+        try:
+            with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
+                self.static_out = self._fwd_bwd(self.static_x)
+                if fused:
+                    self.opt.step()
+        except BaseException:
+            # a failed capture leaves no usable graph: drop it so that the next call captures again (or runs eagerly) from clean state
+            self.graph_a = self.graph_b = None
+            self.static_out = None
+            raise
         if not fused:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):

@@ -10,7 +10,7 @@ import weakref
 import torch
 
 from . import _C
-from ._C import ACT, BnFold, ConvDesc, RbExt, GATHER_CONV, GATHER_TRANSPOSED, PREC_BF16, PREC_F32, call, ptr, stream_ptr
+from ._C import ACT, BnFold, ConvDesc, RbExt, GATHER_CONV, GATHER_TRANSPOSED, PREC_BF16, PREC_F32, call, ptr, ptr_dt, stream_ptr
 
 _ws_cache = {}
 
@@ -101,12 +101,12 @@ class ConvGeom:
 def _desc(g, weight, x, x2, N, H, W, OH, OW, Cout, k_stride, n_stride, gather, bias=None, in_scale=None, in_shift=None,
           in_act=None, out_scale=None, out_act=None, y=None):
     d = ConvDesc()
-    d.x, d.x2 = ptr(x), ptr(x2)
+    d.x, d.x2 = ptr_dt(x), ptr_dt(x2)   # element types travel in d.x_dtype / d.y_dtype below
     d.C1, d.C2 = x.shape[3], (x2.shape[3] if x2 is not None else 0)
     d.w, d.w_stap, d.w_sk, d.w_sn = ptr(weight), g.s_tap, k_stride, n_stride
     d.bias, d.in_scale, d.in_shift = ptr(bias), ptr(in_scale), ptr(in_shift)
     d.in_act, d.out_scale, d.out_act = ACT[in_act], ptr(out_scale), ACT[out_act]
-    d.y = ptr(y)
+    d.y = ptr_dt(y)
     d.N, d.H, d.W, d.OH, d.OW, d.Cout = N, H, W, OH, OW, Cout
     d.KH, d.KW, d.stride, d.pad, d.gather = g.KH, g.KW, g.stride, g.pad, gather
     d.precision = precision
@@ -204,6 +204,12 @@ class _PreparedWeights:
         if self.table is None:
             return None
         return (self.table, [e for e in self.entries.values()])   # the caller (the graph's owner) holds it; nothing here does
+
+    def invalidate(self):
+        """Forget that any buffer is current (a step that stamped them was abandoned before its launches ran, e.g. a failed capture):
+        every convolution transforms its own weights until the next prepare_all()."""
+        for e in self.entries.values():
+            e['stamp'] = None
 
     def weights_written(self):
         """Call after weights were modified through raw pointers (optimizer kernel, collective, graph replay)."""
@@ -389,7 +395,7 @@ def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scal
     if not need:
         return None
     ws = workspace(need, dout.device)
-    call('lvae_conv1x1_gate_bwd_wgrad_f32', C.byref(d), ptr(dout), ptr(ab), ptr(y), ACT[act], ptr(dweight), g.s_ci, g.s_co, ptr(dbias),
+    call('lvae_conv1x1_gate_bwd_wgrad_f32', C.byref(d), ptr(dout), ptr_dt(ab), ptr_dt(y), ACT[act], ptr(dweight), g.s_ci, g.s_co, ptr(dbias),
          ws.data_ptr(), ws.numel(), stream_ptr())
     return dx
 
@@ -607,8 +613,8 @@ def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, db
     ws = workspace(8 * Cn, x.device)
     rows_per_n = M // x.shape[0]
     dtypes = _dt(dh) | (_dt(x) << 1) | (_dt(dx) << 2)
-    call('lvae_affine_act_bwd_parts_f32', ptr(parts), parts.shape[0], ptr(dh), ptr(x), M, Cn, ptr(scale), ptr(shift), ACT[act],
-         ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(drop), rows_per_n, ptr(add), ptr(dx), ws.data_ptr(), ws.numel(),
+    call('lvae_affine_act_bwd_parts_f32', ptr(parts), parts.shape[0], ptr_dt(dh), ptr_dt(x), M, Cn, ptr(scale), ptr(shift), ACT[act],
+         ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), ptr(drop), rows_per_n, ptr(add), ptr_dt(dx), ws.data_ptr(), ws.numel(),
          dtypes, stream_ptr())
     return dx
 
@@ -636,7 +642,7 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=Non
     rows = _C.load().lvae_conv2d_stats_rows(C.byref(d))
     if rows > 0 and out_scale is None and ci_range is None and tuple(xb.shape) == tuple(dx.shape):
         parts = torch.empty((rows, 2, b - a), dtype=torch.float32, device=dy.device)
-        d.stats_out, d.stats_pivot, d.stats_x = ptr(parts), ptr(coef), ptr(xb)
+        d.stats_out, d.stats_pivot, d.stats_x = ptr(parts), ptr(coef), ptr_dt(xb)
         d.stats_mode, d.stats_act, d.stats_x_dtype = 1, ACT[act], _dt(xb)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     return dx, parts
@@ -657,7 +663,7 @@ def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, 
     d.y_dtype = _dt(dy)
     need = _C.load().lvae_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
-    call('lvae_conv2d_wgrad_f32', C.byref(d), ptr(dy), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())
+    call('lvae_conv2d_wgrad_f32', C.byref(d), ptr_dt(dy), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())   # dy's type: d.y_dtype
 
 
 def conv2d_wgrad_grouped(items):
@@ -677,7 +683,7 @@ def conv2d_wgrad_grouped(items):
                   GATHER_TRANSPOSED if g.transposed else GATHER_CONV, None, kw.get('in_scale'), kw.get('in_shift'), kw.get('in_act'))
         d.y_dtype = _dt(dy)
         C.memmove(C.byref(descs, i * C.sizeof(ConvDesc)), C.byref(d), C.sizeof(ConvDesc))
-        dys[i], dws[i], dbs[i] = ptr(dy), ptr(dweight), ptr(dbias)
+        dys[i], dws[i], dbs[i] = ptr_dt(dy), ptr(dweight), ptr(dbias)
     need = _C.load().lvae_conv2d_wgrad_grouped_workspace(descs, n)
     ws = workspace(need, items[0][0].device)
     call('lvae_conv2d_wgrad_grouped_f32', descs, C.cast(dys, C.c_void_p), C.cast(dws, C.c_void_p), C.cast(dbs, C.c_void_p), n,

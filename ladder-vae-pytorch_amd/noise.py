@@ -55,6 +55,44 @@ class PhiloxNoise:
         return self._fill(shape, 'uniform', lo, hi, device)
 
 
+class FrozenNoise:
+    """The on-device draws of the FIRST forward, kept and handed out again in call order by every later forward — of this model or of
+    another one that is given the same object. For tests that compare eager, hipGraph and reduced-precision steps on one noise tape at
+    sizes where no CPU oracle tape exists (tests/test_fullsize_gpu.py)."""
+
+    def __init__(self, seed=0):
+        self.src = PhiloxNoise(seed)
+        self.tape, self.pos, self.recorded = [], 0, False
+
+    def begin(self, device, mask_plan=None):
+        self.pos = 0
+        if not self.recorded:
+            self.src.begin(device, None)   # no mask plan: one draw per call, so that the tape is in call order
+
+    def end(self):
+        if not self.recorded:
+            self.src.end()
+            self.recorded = True
+
+    def _get(self, make):
+        if self.recorded:
+            t = self.tape[self.pos]
+        else:
+            t = make()
+            self.tape.append(t)
+        self.pos += 1
+        return t
+
+    def dropout_mask(self, N, C, p, device):
+        return self._get(lambda: self.src.dropout_mask(N, C, p, device))
+
+    def normal(self, shape_nhwc, device):
+        return self._get(lambda: self.src.normal(shape_nhwc, device))
+
+    def uniform(self, shape, lo, hi, device, channel_last=True):
+        return self._get(lambda: self.src.uniform(shape, lo, hi, device, channel_last))
+
+
 class TapeNoise:
     """entries: the reference's draws in call order, in the reference's own shapes (NCHW / (B,C,1,1) / channel-last).
 

@@ -80,6 +80,12 @@ def flush_wgrad_group():
         K.conv2d_wgrad_grouped(q)
 
 
+def drop_wgrad_group():
+    """Forget the queued weight gradients WITHOUT launching them: the pass they belong to was abandoned (an exception inside a step or
+    inside its capture); their inputs may be tensors of a capture that no longer exists."""
+    _side['group_q'] = []
+
+
 def wgrad(x, dy, w, g, dw, db, **kw):
     rows = _side.get('group_rows')
     if rows is not None and x.shape[0] * x.shape[1] * x.shape[2] <= rows:

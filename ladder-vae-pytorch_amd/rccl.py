@@ -1,14 +1,14 @@
-"""A private RCCL communicator for the gradient exchange INSIDE the captured step graph.
+"""The gradient exchange's communicator: a thin binding of liblvae_hip.so's lvae_allreduce_* entry points (csrc/allreduce.hip), which own
+a private RCCL communicator and the fork / join of the side stream around every bucket.
 
-torch.distributed's ProcessGroupNCCL works for eager collectives, but its bookkeeping is not made for collectives that are captured
-into a hipGraph on a side stream: every collective creates a Work object with events, a watchdog thread polls them, and events recorded
-while a stream is capturing must not be queried — round 3 saw the watchdog abort the process with "operation not permitted on an event
-last recorded in a capturing stream" on exactly this path (a race: most runs pass). Calling ncclAllReduce ourselves on our own
-communicator leaves nothing for a watchdog to look at: the call is a plain kernel launch on the stream we pass, captured like any
-other kernel. (The same reasoning as vLLM's pynccl wrapper.) The process group is still what exchanges the communicator id, broadcasts
-the initial parameters and runs barriers / timing reductions, all eagerly and outside the step.
+Why a communicator of our own instead of torch.distributed's collectives: ProcessGroupNCCL keeps a Work object, events and a polling
+watchdog per collective, and events recorded while a stream is capturing must not be queried — round 3 saw the watchdog abort the process
+with "operation not permitted on an event last recorded in a capturing stream" on exactly this path (a race: most runs pass). An
+ncclAllReduce on our own communicator leaves nothing for a watchdog to look at: it is a plain launch on the stream we pass, captured like
+any other kernel. The process group is still what hands out the communicator id, broadcasts the initial parameters and runs barriers /
+timing reductions, all eagerly and outside the step.
 
-librccl.so is the one torch itself loaded (torch/lib/librccl.so): `backend "nccl" IS RCCL on ROCm`, over xGMI between the GPUs of a node.
+librccl.so is the one torch itself loaded (torch/lib/librccl.so): backend "nccl" IS RCCL on ROCm, over xGMI between the GPUs of a node.
 """
 import ctypes as C
 import os
@@ -16,71 +16,67 @@ import os
 import torch
 import torch.distributed as dist
 
-NCCL_FLOAT32, NCCL_SUM = 7, 0   # rccl.h: ncclDataType_t / ncclRedOp_t
-
-
-class _UniqueId(C.Structure):
-    _fields_ = [('internal', C.c_byte * 128)]   # NCCL_UNIQUE_ID_BYTES
-
-
-_lib = None
-
-
-def _load():
-    global _lib
-    if _lib is None:
-        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        lib = C.CDLL(path)
-        lib.ncclGetUniqueId.restype = C.c_int
-        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
-        lib.ncclCommInitRank.restype = C.c_int
-        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
-        lib.ncclAllReduce.restype = C.c_int
-        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        lib.ncclCommDestroy.restype = C.c_int
-        lib.ncclCommDestroy.argtypes = [C.c_void_p]
-        lib.ncclGetErrorString.restype = C.c_char_p
-        lib.ncclGetErrorString.argtypes = [C.c_int]
-        _lib = lib
-    return _lib
+from . import _C
 
 
 class RcclError(RuntimeError):
     pass
 
 
-def _chk(rc, what):
-    if rc != 0:
-        raise RcclError('%s failed: %s' % (what, _load().ncclGetErrorString(rc).decode()))
+def librccl_path():
+    return os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+
+
+def _call(name, *args):
+    try:
+        _C.call(name, *args)
+    except _C.LvaeHipError as e:
+        raise RcclError(str(e)) from None
 
 
 class Comm:
-    """One communicator over the ranks of `group` (default: the world). The id is created by rank 0 and handed out through the
-    process group (an eager broadcast of 128 bytes). The current device must be this rank's GPU."""
+    """One communicator over the ranks of `group` (default: the world). The id is created by rank 0 and handed out through the process
+    group (an eager broadcast of 128 bytes). The current device must be this rank's GPU. ncclCommInitRank is a collective: every rank of
+    the group must construct its Comm."""
 
     def __init__(self, group=None):
-        lib = _load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        uid = _UniqueId()
+        path = librccl_path().encode()
+        uid = (C.c_ubyte * 128)()
         if self.rank == 0:
-            _chk(lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+            _call('lvae_allreduce_unique_id', path, C.cast(uid, C.c_void_p))
         dev = torch.device('cuda', torch.cuda.current_device())
-        t = torch.frombuffer(bytearray(bytes(uid.internal)), dtype=torch.uint8).to(dev)
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(t, src=src, group=group)
-        raw = bytes(t.cpu().numpy().tobytes())
-        C.memmove(C.byref(uid), raw, 128)
-        self.comm = C.c_void_p()
-        _chk(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        raw = (C.c_ubyte * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        self.handle = C.c_void_p()
+        _call('lvae_allreduce_init', path, C.cast(raw, C.c_void_p), self.world, self.rank, C.byref(self.handle))
 
-    def all_reduce_(self, tensor, stream=None):
-        """In-place float32 SUM over the ranks, enqueued on `stream` (default: torch's current stream). A plain launch: capturable."""
+    @staticmethod
+    def _check(tensor):
         if tensor.dtype != torch.float32 or not tensor.is_contiguous() or not tensor.is_cuda:
-            raise RcclError('all_reduce_ takes a contiguous float32 device tensor')
-        st = (stream or torch.cuda.current_stream(tensor.device)).cuda_stream
-        _chk(_load().ncclAllReduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self.comm, st), 'ncclAllReduce')
+            raise RcclError('the exchange takes a contiguous float32 device tensor')
+
+    def enqueue(self, tensor, launch_stream, side_stream, scratch=None):
+        """In-place float32 SUM over the ranks on `side_stream`, behind everything issued on `launch_stream` so far (the library forks).
+        scratch (same size): the out-of-place form for one-rank rehearsals (an in-place all-reduce of one rank enqueues nothing)."""
+        self._check(tensor)
+        if scratch is not None and (scratch.numel() < tensor.numel() or scratch.dtype != torch.float32 or not scratch.is_cuda):
+            raise RcclError('scratch must be a float32 device tensor at least as large as the bucket')
+        _call('lvae_allreduce_enqueue', self.handle, tensor.data_ptr(), tensor.numel(), scratch.data_ptr() if scratch is not None else None,
+              launch_stream.cuda_stream, side_stream.cuda_stream)
+
+    def wait(self, launch_stream, side_stream):
+        """`launch_stream` waits for everything enqueued on `side_stream` so far."""
+        _call('lvae_allreduce_wait', self.handle, launch_stream.cuda_stream, side_stream.cuda_stream)
+
+    def all_reduce_(self, tensor, stream=None, scratch=None):
+        """The same exchange on ONE stream (default: torch's current stream), no fork: a plain launch, capturable."""
+        st = stream or torch.cuda.current_stream(tensor.device)
+        self.enqueue(tensor, st, st, scratch)
 
     def destroy(self):
-        if self.comm:
-            _load().ncclCommDestroy(self.comm)
-            self.comm = C.c_void_p()
+        if self.handle:
+            _C.load().lvae_allreduce_destroy(self.handle)
+            self.handle = C.c_void_p()

@@ -67,6 +67,9 @@ def main():
         assert ar.comm is not None, ar.comm_error          # the captured exchange never goes through ProcessGroupNCCL
         step = TrainStep(m, opt, use_graph=True, allreduce=ar)
         assert step.overlap and m.grad_tracker is ar and len(ar.buckets) >= 3
+        # the capture probe's graph really held work (with one rank an in-place all-reduce enqueues nothing and torch
+        # warned "The CUDA Graph is empty"; the one-rank rehearsal now uses the out-of-place form: RCCL's kernel + a device copy)
+        assert ar.scratch is not None and ar.probe_nodes_ran
         losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
         torch.cuda.synchronize()
         assert step.graph_a is not None and step.graph_b is None      # ONE graph: backward, exchange and Adamax together
@@ -82,19 +85,19 @@ def main():
         ldist.broadcast_flat(arena.params)
         ar = ldist.GradAllReduce(arena.grads, segments=arena.segments, bucket_mb=0.25)
         assert ar.comm is not None, ar.comm_error          # buckets go through the private RCCL communicator (rccl.py)
-        real = ar.comm.all_reduce_
+        real = ar.comm.enqueue
 
         def refusing(*a, **kw):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('operation not permitted when stream is capturing (simulated by the test)')
             return real(*a, **kw)
 
-        ar.comm.all_reduce_ = refusing
+        ar.comm.enqueue = refusing
         step = TrainStep(m, opt, use_graph=True, allreduce=ar)     # its capture probe meets the refusal: split mode from the start
         assert not step.overlap and step.fallback_reason and m.grad_tracker is None
         losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
         torch.cuda.synchronize()
-        ar.comm.all_reduce_ = real
+        ar.comm.enqueue = real
         assert step.graph_a is not None and step.graph_b is not None
         assert 'split' in step.exchange_description()
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'reason': step.fallback_reason})

@@ -146,6 +146,57 @@ def test_bf16_training_step_is_within_the_stated_tolerance_of_the_fp32_oracle(ca
     assert rec['grad_worst_rel_l2'] > 1e-4                      # ... and it really ran in reduced precision
 
 
+def test_celeba20_shard_step_at_its_real_per_gpu_batch():
+    """BASELINE configs[4] at its real per-GPU batch (128 images of 64x64, 20 layers): a different N*H*W per level than the batch-16 oracle
+    case above, hence other kernel variants. No CPU oracle at this size (minutes per step); the properties the step must have on one noise
+    tape and one set of weights: every scalar finite, the replayed hipGraph equals the eager launches, and the bf16 step's ELBO is
+    within SURVEY.md §8(c)'s 1e-2 of the fp32 HIP step (which the smaller cases pin to the oracle)."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd import configs
+    from lvae_amd import kernels as K
+    from lvae_amd.engine import TrainStep
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import FrozenNoise
+    from lvae_amd.optim import Adamax
+    cfg = configs.CELEBA20
+    noise = FrozenNoise(seed=9)                        # the first forward's draws, replayed by every later forward of all three models
+    x = configs.synthetic_images(cfg, 128, torch.Generator().manual_seed(77)).cuda()
+    torch.manual_seed(42)
+    init = {k: v.clone() for k, v in LadderVAE(**cfg).state_dict().items()}
+    res = {}
+    for mode, dtype, use_graph in (('f32-eager', 'f32', False), ('f32-graph', 'f32', True), ('bf16-graph', 'bf16', True)):
+        model = LadderVAE(**cfg)
+        model.load_state_dict(init)
+        model.cuda().train()
+        model.compute_dtype = dtype
+        model.noise = noise
+        K.prepared.entries.clear()
+        K.prepared.table = None
+        step = TrainStep(model, Adamax(model, lr=0.0), use_graph=use_graph, eager_warmup=2)
+        outs = []
+        for i in range(4 if use_graph else 2):         # lr 0 and one tape: every step must give the same numbers
+            outs.append({k: float(v) for k, v in step(x).items() if k in ('loss', 'elbo', 'recons', 'kl')})
+        torch.cuda.synchronize()
+        res[mode] = outs[-1]
+        gn = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters() if p.grad is not None) ** 0.5
+        res[mode]['gradnorm'] = gn
+        for k, v in res[mode].items():
+            assert v == v and abs(v) < 1e30, (mode, k, v)
+        del step, model
+    K.prepared.entries.clear()
+    K.prepared.table = None
+    K.set_precision('f32')
+    for k in ('loss', 'elbo', 'recons', 'kl'):
+        a, b = res['f32-eager'][k], res['f32-graph'][k]
+        assert abs(a - b) <= 1e-6 * abs(a), (k, a, b)              # same kernels, same order: the graph replays the eager step
+    assert abs(res['f32-eager']['gradnorm'] - res['f32-graph']['gradnorm']) <= 1e-6 * res['f32-eager']['gradnorm']
+    for k in ('loss', 'elbo', 'recons'):
+        a, b = res['f32-graph'][k], res['bf16-graph'][k]
+        assert abs(a - b) <= 1e-2 * abs(a), (k, a, b)
+    assert abs(res['f32-graph']['gradnorm'] - res['bf16-graph']['gradnorm']) <= 5e-2 * res['f32-graph']['gradnorm']
+    _report['cfg5_celeba20_b128/properties'] = res
+
+
 def test_iw_1000_sample_evaluation_on_the_64x64_20_layer_model():
     """BASELINE configs[4]'s evaluation (1000-sample importance-weighted bound, evaluate.py:30,56-66) on its architecture: bottom-up once,
     one captured sample graph replayed 1000 times, online log-sum-exp. No oracle at this size (1000 CPU forwards); the properties the

@@ -136,6 +136,67 @@ def test_trainstep_graph_and_side_stream_match_eager():
         torch.testing.assert_close(b0[k].float(), b1[k].float(), rtol=1e-5, atol=1e-6)
 
 
+def test_exception_inside_a_captured_backward_leaves_a_clean_state(monkeypatch):
+    """an exception in the middle of the CAPTURED backward (here: a kernel wrapper that refuses while the stream is capturing)
+    must leave nothing behind that a later step trips over — no queued weight gradients launched on behalf of the abandoned pass, no
+    transformed-weight buffer marked current for a launch that never ran, no half-built graph. The same TrainStep then captures again
+    and ends up with exactly the parameters of a run that never failed."""
+    import lvae_amd  # noqa: F401
+    from lvae_amd import kernels as K
+    from lvae_amd import ops
+    from lvae_amd.models.lvae import LadderVAE
+    from lvae_amd.noise import PhiloxNoise
+    from lvae_amd.optim import Adamax
+    from lvae_amd.engine import TrainStep
+    g = load_golden('tiny_cifar')
+    xs = [torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(i)).cuda() for i in range(5)]
+
+    def fresh():
+        m = LadderVAE(**g.cfg)
+        m.load_state_dict(g.state_dict())
+        m.cuda().train()
+        m.noise = PhiloxNoise(seed=7)
+        return m, TrainStep(m, Adamax(m, lr=1e-3), use_graph=True, eager_warmup=2)
+
+    m0, s0 = fresh()
+    for x in xs:
+        s0(x)
+    torch.cuda.synchronize()
+    ref = m0.arena.params.clone()
+
+    m1, s1 = fresh()
+    s1(xs[0])
+    s1(xs[1])
+    real = K.affine_act_bwd_parts
+    real_plain = K.affine_act_bwd
+
+    def refusing(*a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('simulated failure in the middle of the captured backward')
+        return real(*a, **kw)
+
+    def refusing_plain(*a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('simulated failure in the middle of the captured backward')
+        return real_plain(*a, **kw)
+
+    monkeypatch.setattr(K, 'affine_act_bwd_parts', refusing)
+    monkeypatch.setattr(K, 'affine_act_bwd', refusing_plain)
+    with pytest.raises(RuntimeError, match='simulated failure'):
+        s1(xs[2])
+    monkeypatch.setattr(K, 'affine_act_bwd_parts', real)
+    monkeypatch.setattr(K, 'affine_act_bwd', real_plain)
+    torch.cuda.synchronize()
+    assert s1.graph_a is None and not ops._side.get('group_q')
+    assert all(e['stamp'] is None for e in K.prepared.entries.values())
+    m1.global_step -= 1            # the failed call counted a step that did not happen
+    for x in xs[2:]:
+        s1(x)                      # captures again, then replays
+    torch.cuda.synchronize()
+    assert s1.graph_a is not None
+    assert float((m1.arena.params - ref).abs().max()) < 1e-6
+
+
 def test_cfg1_mnist3_batch64_matches_reference():
     """BASELINE configs[0]: static-MNIST-shaped 3-layer LVAE, batch 64; weights rebuilt from the reference's seed."""
     import lvae_amd  # noqa: F401
