@@ -172,7 +172,10 @@ __device__ __forceinline__ void rb_reduce_parts(const float* __restrict__ parts,
 // partial tiles are summed through LDS in the epilogue. The small 1x1 gate GEMMs keep the 2 x 2 layout with their (pre-split) weights
 // in registers. Everything an epilogue needs from memory (bias, Dropout2d mask rows, pivots, BatchNorm input rows, residual rows) is
 // requested BEFORE the reduction loop.
-template <int SPLIT, int MI, int PRO, int EPI>
+// ELU: every activation id the launch uses is LVAE_ACT_ELU (the model's default), known at compile time. With a run-time id each of the
+// kernel's ~40 four-value activation calls is a chain of scalar compares and TAKEN branches, and with one wave per SIMD a taken branch
+// costs a refetch (~20-30 cycles): the staging segment held 172 branch instructions and ran at ~9 cycles per executed instruction.
+template <int SPLIT, int MI, int PRO, int EPI, bool ELU>
 __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   static_assert(MI == 1, "64-pixel tiles");
   constexpr int BM = 64, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
@@ -186,6 +189,8 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
 
   const lvae_conv_desc& d = a.d;
   const lvae_rb_ext& e = a.e;
+  const int in_act = ELU ? LVAE_ACT_ELU : d.in_act, stats_act = ELU ? LVAE_ACT_ELU : d.stats_act;
+  const int gate_act = ELU ? LVAE_ACT_ELU : e.act, bwd_act = ELU ? LVAE_ACT_ELU : e.bwd_act;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int bid = blockIdx.x;
@@ -209,6 +214,13 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     }
   };
   RB_STAMP_DECL;
+#ifdef LVAE_RB_DBG_REPS
+  // instrument only: the whole body twice in one launch, stamps of the LAST pass (is a phase slower the first time its code is fetched?)
+  const int rb_reps = a.flip >= 0 ? LVAE_RB_DBG_REPS : 1;
+#pragma unroll 1
+  for (int rb_rep = 0; rb_rep < rb_reps; ++rb_rep) {
+  rb_bar();
+#endif
   RB_STAMP(0);
   // ---- L2 warm-up. Every convolution of a step has weights of its own, so the 221 KB this workgroup streams are cold in its XCD's L2
   // when the kernel starts (in-step the launches measured ~4 us longer than back to back on one layer): each wave touches one word of
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       f32x4 v = xv[q];
-      if (has_tf) v = act_fwd4(v * sc + sh, d.in_act);
+      if (has_tf) v = act_fwd4(v * sc + sh, in_act);
       put_interior(q, ok[q] ? v : zero4);
     }
     RB_STAMP(10);
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     RB_STAMP(1);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4 g = gv[q] * rb_act_grad4(xv[q] * sc + sh, e.bwd_act);
+      const f32x4 g = gv[q] * rb_act_grad4(xv[q] * sc + sh, bwd_act);
       f32x4 v = (g - c1 - (xv[q] - mu) * rs * c2) * sc * dm[q];
       if (!ok[q]) v = zero4;
       if (ok[q] && e.xt_out) store_wt4(e.xt_out + grow[q] * 64 + c4, v);
@@ -398,8 +410,8 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
         da[j] = gs;
         db[j] = gs * (1.f - s);
       }
-      da = da * rb_act_grad4(aa[q], e.act);
-      db = db * act_fwd4(aa[q], e.act);
+      da = da * rb_act_grad4(aa[q], gate_act);
+      db = db * act_fwd4(aa[q], gate_act);
       if (!ok[q]) da = db = zero4;
       if (ok[q] && e.dab) {
         store_wt4(e.dab + grow[q] * 128 + c4, da);
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
             st1 += dl;
             st2 += dl * dl;
           } else {
-            const f32x4 g = v * rb_act_grad4(ep_sx[q] * ep_piv + ep_bsh, d.stats_act);
+            const f32x4 g = v * rb_act_grad4(ep_sx[q] * ep_piv + ep_bsh, stats_act);
             st1 += g;
             st2 += g * (ep_sx[q] - ep_bmu) * ep_brs;
           }
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
           store_wt4(e.ab + grow[q] * 128 + c4, av);
           store_wt4(e.ab + grow[q] * 128 + 64 + c4, bv);
         }
-        f32x4 o = act_fwd4(av, e.act);
+        f32x4 o = act_fwd4(av, gate_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] *= sigmoidf_(bv[j]);
         o += ep_res[q];
@@ -676,6 +688,9 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   }
   if (pf_sum == 1.2345678e-30f) scr[2047] = pf_sum;   // keeps the warm-up loads alive (never true for weight bytes read as floats, harmless if it were)
   RB_STAMP(7);
+#ifdef LVAE_RB_DBG_REPS
+  }
+#endif
   RB_STAMP_FLUSH;
 }
 
@@ -750,9 +765,9 @@ static bool rb_plan(const lvae_conv_desc* d, RbArgs& a, int& mi) {
   return rb_lds_bytes(rb_split(d), mi, a.halo_px, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_GATE) <= 160 * 1024;
 }
 
-template <int SPLIT, int MI, int PRO, int EPI>
+template <int SPLIT, int MI, int PRO, int EPI, bool ELU>
 static int rb_launch(const RbArgs& a, hipStream_t s) {
-  auto kern = rb_conv_kernel<SPLIT, MI, PRO, EPI>;
+  auto kern = rb_conv_kernel<SPLIT, MI, PRO, EPI, ELU>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -767,13 +782,30 @@ static int rb_launch(const RbArgs& a, hipStream_t s) {
   return 0;
 }
 
+// every activation id this launch will look at is ELU (ids of features the launch does not use are ignored)
+static bool rb_all_elu(const RbArgs& a) {
+  const lvae_conv_desc& d = a.d;
+  const lvae_rb_ext& e = a.e;
+  const auto elu = [](int act) { return act == LVAE_ACT_ELU; };
+  if (e.prologue == LVAE_RB_PRO_AFFINE && (d.in_scale != nullptr || a.f.parts != nullptr) && !elu(d.in_act)) return false;
+  if (e.prologue == LVAE_RB_PRO_BN_APPLY && !elu(e.bwd_act)) return false;
+  if ((e.prologue == LVAE_RB_PRO_GATE_BWD || e.epilogue == LVAE_RB_EPI_GATE) && !elu(e.act)) return false;
+  if (d.stats_out != nullptr && d.stats_mode == LVAE_STATS_BN_BWD && !elu(d.stats_act)) return false;
+  return true;
+}
+
+template <int SPLIT, int MI, bool ELU>
+static int rb_dispatch2(const RbArgs& a, hipStream_t s) {
+  const int pro = a.e.prologue, epi = a.e.epilogue;
+  if (pro == LVAE_RB_PRO_AFFINE) return epi == LVAE_RB_EPI_GATE ? rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_GATE, ELU>(a, s)
+                                                                  : rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_PLAIN, ELU>(a, s);
+  if (pro == LVAE_RB_PRO_BN_APPLY) return rb_launch<SPLIT, MI, LVAE_RB_PRO_BN_APPLY, LVAE_RB_EPI_PLAIN, ELU>(a, s);
+  return rb_launch<SPLIT, MI, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_PLAIN, ELU>(a, s);
+}
+
 template <int SPLIT, int MI>
 static int rb_dispatch(const RbArgs& a, hipStream_t s) {
-  const int pro = a.e.prologue, epi = a.e.epilogue;
-  if (pro == LVAE_RB_PRO_AFFINE) return epi == LVAE_RB_EPI_GATE ? rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_GATE>(a, s)
-                                                                  : rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_PLAIN>(a, s);
-  if (pro == LVAE_RB_PRO_BN_APPLY) return rb_launch<SPLIT, MI, LVAE_RB_PRO_BN_APPLY, LVAE_RB_EPI_PLAIN>(a, s);
-  return rb_launch<SPLIT, MI, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_PLAIN>(a, s);
+  return rb_all_elu(a) ? rb_dispatch2<SPLIT, MI, true>(a, s) : rb_dispatch2<SPLIT, MI, false>(a, s);
 }
 
 }  // namespace lvae

@@ -34,6 +34,9 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+ACTS = {'elu': F.elu, 'relu': F.relu, 'leakyrelu': lambda t: F.leaky_relu(t, 0.01), 'selu': F.selu}
+
+
 def make_block(N, H, W, seed):
     g = torch.Generator().manual_seed(seed)
     C = 64
@@ -53,30 +56,32 @@ def make_block(N, H, W, seed):
     return p
 
 
-def reference(p):
+def reference(p, act='elu'):
     """float64 torch statement of the block and of everything the kernels hand to each other"""
     o = types.SimpleNamespace()
+    fa = ACTS[act]
     bn = lambda t, ga, be: F.batch_norm(t, None, None, ga, be, True, 0.1, 1e-5)
-    o.h1 = F.elu(bn(p.x, p.g1, p.be1))
+    o.h1 = fa(bn(p.x, p.g1, p.be1))
     o.y1 = (F.conv2d(o.h1, p.w1, p.b1, padding=1) * p.m1[:, :, None, None])
-    o.h2 = F.elu(bn(o.y1, p.g2, p.be2))
+    o.h2 = fa(bn(o.y1, p.g2, p.be2))
     o.y2 = (F.conv2d(o.h2, p.w2, p.b2, padding=1) * p.m2[:, :, None, None])
     o.ab = F.conv2d(o.y2, p.wg, p.bg)
     a, b = o.ab.chunk(2, 1)
-    o.out = F.elu(a) * torch.sigmoid(b) + p.x
+    o.out = fa(a) * torch.sigmoid(b) + p.x
     for t in (o.h1, o.y1, o.h2, o.y2, o.ab):
         t.retain_grad()
     o.out.backward(p.dout)
     return o
 
 
-@pytest.mark.parametrize('prec', ['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(256, 4, 4), (64, 8, 8), (37, 2, 2), (7, 8, 8), (130, 4, 4), (1, 2, 2), (300, 8, 8)])
-def test_fused_block_forward_and_backward(K, shape, prec):
+@pytest.mark.parametrize('shape,prec,act', [(s, pr, 'elu') for pr in ('f32', 'bf16') for s in
+                                            [(256, 4, 4), (64, 8, 8), (37, 2, 2), (7, 8, 8), (130, 4, 4), (1, 2, 2), (300, 8, 8)]] +
+                         [((40, 4, 4), 'f32', 'selu'), ((9, 8, 8), 'f32', 'leakyrelu'), ((33, 2, 2), 'f32', 'relu')])   # the run-time-activation build
+def test_fused_block_forward_and_backward(K, shape, prec, act):
     N, H, W = shape
     C = 64
     p = make_block(N, H, W, 7 * N + H)
-    o = reference(p)
+    o = reference(p, act)
     tol = 1.0 if prec == 'f32' else 4000.0   # bf16 operands: 2^-9 relative per product instead of 2^-24
     K.set_precision(prec)
     try:
@@ -92,9 +97,9 @@ def test_fused_block_forward_and_backward(K, shape, prec):
         m1, m2 = p.m1.float().to(dev), p.m2.float().to(dev)
         # ---- forward: BN1 statistics by the stand-alone kernel (first block of a chain), then the two fused launches
         coef1 = K.bn_stats(x, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
-        y1, parts2, _ = K.rb_conv(x, w1, ge1, f(p.b1), 'elu', m1, coef=coef1, stats_pivot=bn2.running_mean)
+        y1, parts2, _ = K.rb_conv(x, w1, ge1, f(p.b1), act, m1, coef=coef1, stats_pivot=bn2.running_mean)
         pivot = coef1[2]
-        y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, w2, ge2, f(p.b2), 'elu', m2, wg, geg, f(p.bg), x, 'elu',
+        y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, w2, ge2, f(p.b2), act, m2, wg, geg, f(p.bg), x, act,
                                                     in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot)
         torch.cuda.synchronize()
         assert rel(nchw(y1), o.y1.detach()) < 2e-6 * tol
@@ -119,11 +124,11 @@ def test_fused_block_forward_and_backward(K, shape, prec):
         # ---- backward
         dout = nhwc(p.dout)
         assert K.bn_coef_block(*coef2) and K.bn_coef_block(*coef1)
-        dab, dy2, dh2, bparts2 = K.rb_gate_dgrad(dout, ab, wg, geg, 'elu', m2, w2, ge2, bn_bwd=(y1, coef2[0], 'elu'))
+        dab, dy2, dh2, bparts2 = K.rb_gate_dgrad(dout, ab, wg, geg, act, m2, w2, ge2, bn_bwd=(y1, coef2[0], act))
         dg2, db2 = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)   # accumulated into
-        dy1, dh1, bparts1 = K.rb_apply_dgrad(bparts2, dh2, y1, coef2[0], 'elu', dg2, db2, m1, w1, ge1, bn_bwd=(x, coef1[0], 'elu'))
+        dy1, dh1, bparts1 = K.rb_apply_dgrad(bparts2, dh2, y1, coef2[0], act, dg2, db2, m1, w1, ge1, bn_bwd=(x, coef1[0], act))
         dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-        dx = K.affine_act_bwd_parts(bparts1, dh1, x, coef1[0], coef1[1], 'elu', coef1[2], coef1[3], dg1, db1, add=dout)
+        dx = K.affine_act_bwd_parts(bparts1, dh1, x, coef1[0], coef1[1], act, coef1[2], coef1[3], dg1, db1, add=dout)
         torch.cuda.synchronize()
         btol = tol * 3
         assert rel(nchw(dab), o.ab.grad) < 2e-6 * btol
