@@ -39,11 +39,11 @@ F_ALG_PER_IMAGE = 10.563e9     # FLOP, fwd + dgrad + wgrad of every convolution 
 B_ALG_PER_IMAGE = 115.93e6     # bytes, fp32 activations in/out of every convolution, fwd + dgrad + wgrad
 B_ALG_PER_IMAGE_BF16 = 57.96e6  # bytes, the same tensors stored in bf16 (BASELINE.md §4 counts 2 B per element)
 PEAK_MFMA_BF16 = 2500.0        # TFLOP/s dense, MI355X_MICROARCH.md
-# committed rocprofv3 summaries of this command (newest round first; tools/r03_final.sh writes them)
-ROCPROF_SUMMARIES = ('profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
-PMC_SUMMARIES = ('profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
-PMC_SUMMARIES_BF16 = ('profiles/r03_pmc/hbm_traffic_bf16.json',)
-ROCPROF_SUMMARIES_BF16 = ('profiles/r03_bf16_kernel_by_grid.txt', 'profiles/r02_bf16_kernel_by_grid.txt')
+# committed rocprofv3 summaries of this command (newest round first; tools/r04_final.sh writes them)
+ROCPROF_SUMMARIES = ('profiles/r04_kernel_by_grid.txt', 'profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
+PMC_SUMMARIES = ('profiles/r04_pmc/hbm_traffic.json', 'profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
+PMC_SUMMARIES_BF16 = ('profiles/r04_pmc/hbm_traffic_bf16.json', 'profiles/r03_pmc/hbm_traffic_bf16.json')
+ROCPROF_SUMMARIES_BF16 = ('profiles/r04_bf16_kernel_by_grid.txt', 'profiles/r03_bf16_kernel_by_grid.txt', 'profiles/r02_bf16_kernel_by_grid.txt')
 
 
 def first_existing(paths):
@@ -82,7 +82,7 @@ def conv_roofline(model, x):
     orig = K.call
 
     def timed_call(name, *args):
-        if name not in ('lvae_conv2d_f32', 'lvae_conv1x1_gate_f32'):
+        if name not in ('lvae_conv2d_f32', 'lvae_conv1x1_gate_f32', 'lvae_resblock_conv_f32'):
             return orig(name, *args)
         d = args[0]._obj
         flops = 2.0 * d.N * d.OH * d.OW * d.Cout * (d.C1 + d.C2) * d.KH * d.KW
@@ -92,6 +92,18 @@ def conv_roofline(model, x):
         nbytes = ((2.0 if d.x_dtype else 4.0) * d.N * d.H * d.W * (d.C1 + d.C2) + (2.0 if d.y_dtype else 4.0) * d.N * d.OH * d.OW * d.Cout +
                   4.0 * d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
         key = 'conv %dx%d s%d %d->%d @%dx%dx%d' % (d.KH, d.KW, d.stride, d.C1 + d.C2, d.Cout, d.N, d.OH, d.OW)
+        if name == 'lvae_resblock_conv_f32':
+            # fused residual-block launches (resblock_img.hip, or the Winograd kernel with the gate behind it): a group of their own per
+            # prologue / epilogue; the 1x1 gate GEMM's work and tensors are counted with the launch that contains it
+            e = args[1]._obj if args[1] is not None else None
+            pro, epi = (e.prologue, e.epilogue) if e is not None else (0, 0)
+            px = float(d.N) * d.OH * d.OW
+            if epi == 1 or pro == 2:
+                flops += 2.0 * px * 64 * 128
+                nbytes += 4.0 * px * (128 + 64 + (64 if epi == 1 else 128))
+            if pro == 1:
+                nbytes += 4.0 * px * 64 * 2
+            key = 'fused ' + ('gate-bwd + ' if pro == 2 else 'bn-apply + ' if pro == 1 else '') + key + (' + gate' if epi == 1 else '')
         if name == 'lvae_conv2d_f32':
             variants[key] = K._C.load().lvae_conv2d_variant(args[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -132,8 +144,11 @@ def pmc_traffic(dom_key, kname, wgs, paths=PMC_SUMMARIES):
         if dom_key != 'conv 3x3 s1 64->64 @256x16x16' or not os.path.exists(path):
             continue
         meta = json.load(open(path))
-        prefix = kname.split('<')[0]
+        prefix = kname if kname.endswith('<false>') else kname.split('<')[0]
         vals = [v['hbm_bytes_per_launch'] for k, v in meta['kernels'].items() if k.startswith(prefix) and k.endswith('@%d workgroups' % wgs)]
+        if not vals and prefix != kname.split('<')[0]:   # summaries of earlier rounds: the kernel was not a template yet
+            prefix = kname.split('<')[0]
+            vals = [v['hbm_bytes_per_launch'] for k, v in meta['kernels'].items() if k.startswith(prefix) and k.endswith('@%d workgroups' % wgs)]
         if vals:
             return sum(vals) / len(vals), '%s (%s)' % (rel, meta.get('scope', 'single-layer micro-benchmark tools/conv_bench.py, not the whole step'))
     return None, None
@@ -307,7 +322,7 @@ def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
     V = K._C
     if kind == V.VARIANT_WINO_SIX:   # Winograd F(2x2,3x3): 16/36 of the direct multiplies, each as six bf16-piece products on the bf16 MFMA
         issued, peak, unit = f_alg * 16.0 / 36.0 * 6.0, PEAK_MFMA_BF16, 'bf16 MFMA (v_mfma_f32_32x32x16_bf16), six exact bf16-piece products per fp32 product'
-        kname = 'conv3x3_wino2_kernel'
+        kname = 'conv3x3_wino2_kernel<false>'
     elif kind == V.VARIANT_WINO_F32:
         issued, peak, unit, kname = f_alg * 16.0 / 36.0, PEAK_MFMA_F32, 'fp32 MFMA (v_mfma_f32_32x32x2_f32)', 'conv3x3_wino_kernel<64, 2, 1, false>'
     elif kind == V.VARIANT_BF16_DIRECT:
@@ -330,7 +345,8 @@ def dominant_kernel_record(dkey, dn, dflops, dbytes, dms, kind, dtype):
         'effective_frac_of_fp32_mfma_peak': f_alg / t / 1e12 / PEAK_MFMA_F32,
         'algorithmic_bytes_per_launch': b_alg, 'hbm_gb_per_s': hbm, 'hbm_frac_of_peak': hbm / PEAK_HBM,
         'launches_per_step': dn, 'avg_launch_us': t * 1e6,
-        'avg_launch_us_rocprof': rocprof_avg_us(kname.split('<')[0], wgs, ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16),
+        'avg_launch_us_rocprof': (rocprof_avg_us(kname, wgs, ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16) if kname.endswith('<false>') else None) or
+                                 rocprof_avg_us(kname.split('<')[0], wgs, ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16),
         'rocprof_summary': first_existing(ROCPROF_SUMMARIES if dtype == 'f32' else ROCPROF_SUMMARIES_BF16),
         'note': 'frac = FLOPs the matrix unit ISSUES per launch / avg launch time / that unit\'s dense peak. effective_tflops counts the '
                 'ALGORITHMIC direct-convolution FLOPs (2*N*OH*OW*Cout*Cin*9) the launch replaces. The kernel is bound by neither pipe peak: '

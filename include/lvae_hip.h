@@ -287,6 +287,11 @@ typedef struct lvae_rb_ext {
 size_t lvae_resblock_gate_workspace(const lvae_conv_desc* g);
 int lvae_resblock_gate_prepare_entry(const lvae_conv_desc* g, void* entry);
 int32_t lvae_resblock_conv_rows(const lvae_conv_desc* d);
+/* Rows of out_stats (= workgroups) of an LVAE_RB_EPI_GATE launch. Besides the whole-image shapes (= lvae_resblock_conv_rows) the forward
+ * conv + gate fusion exists for the shapes of the 256-pixel six-product Winograd kernel (fp32, 64 -> 64 channels: the 16x16 and 32x32 levels at
+ * batch 256; lvae_conv2d_variant(d) == LVAE_VARIANT_WINO_SIX with at least 256 workgroups): attach THAT kernel's workspace
+ * (lvae_conv2d_workspace / lvae_conv2d_prepare_entry) to d before asking and before the launch. 0: use lvae_conv2d_f32 + lvae_conv1x1_gate_f32. */
+int32_t lvae_resblock_conv_gate_rows(const lvae_conv_desc* d);
 size_t lvae_resblock_conv_workspace(const lvae_conv_desc* d);
 int lvae_resblock_conv_prepare_entry(const lvae_conv_desc* d, void* entry);
 int lvae_resblock_conv_f32(const lvae_conv_desc* d, const lvae_rb_ext* ext, void* stream);

@@ -85,6 +85,7 @@ SIGNATURES = {
     'lvae_resblock_gate_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_resblock_gate_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_resblock_conv_rows': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_resblock_conv_gate_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_resblock_conv_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_resblock_conv_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_resblock_conv_f32': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(RbExt), _P]),

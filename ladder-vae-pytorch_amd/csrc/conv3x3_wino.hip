@@ -39,6 +39,16 @@ struct WinoArgs {
   uint32_t m_thw, m_per_img, m_halo_w, m_tiles_x, m_wt_per_img, m_tw;
   lvae_bn_fold f;   // copy of *d.in_fold (f.parts == nullptr: none): BatchNorm finalize of the input in the prologue, wino_fold_bn
   int store_pivot;  // the statistics epilogue also stores its pivot behind the partial rows (for a consumer that folds the finalize)
+  // GateLayer2d fused behind the convolution (conv3x3_wino2_kernel<true>, lvae_resblock_conv_f32 with LVAE_RB_EPI_GATE): pre-split 1x1
+  // weights [k-step 4][32-column tile 4][piece 3][lane][8] (resblock_img.hip's layout), bias [128], residual rows, outputs
+  const __bf16* g_ws;
+  const float* g_bias;
+  const float* g_res;
+  float* g_ab;
+  float* g_out;
+  float* g_stats;
+  const float* g_pivot;
+  int g_act;
 };
 
 // Six-product form (conv3x3_wino_kernel<.., SPL = true>): U[p][k][n] split exactly into three bf16 pieces, stored in the B-fragment order of
@@ -629,6 +639,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
 
 constexpr int W2_LDS_R = 8 * 2 * 32 * WLDO * 4;  // bytes of the partial-sum exchange of one block
 
+// GATE: the block's GateLayer2d (lib/nn.py:118-126) and residual add run behind the convolution, per 128-pixel block: the store pass keeps
+// its four rows of y2 = (conv + bias) * Dropout2d mask in registers (besides storing them for the backward), the rows are split into three
+// bf16 planes over the dead partial sums, the 8 waves run the 128 x 128 x 64 gate GEMM as six-product MFMAs (wave = 32 rows x {32 a-columns,
+// the matching 32 b-columns}), and a second pass stores ab, out = act(a) * sigmoid(b) + x and the BatchNorm partials of out. There is no
+// BatchNorm between conv2 and the gate, so nothing crosses workgroups: the 85 MB gate launch of a 256x16x16 block (25 us in the step)
+// becomes ~50 MB of stores and one residual read inside a launch that is already there.
+template <bool GATE>
 __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
   constexpr int CIN = 64, WLDA = CIN + 4, NSLICE = CIN / 16, CW = 64, C4N = CW / 4, PG = 512 / C4N, NH = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -882,7 +899,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
   for (int m = 0; m < 2; ++m) {
     if (m) {
       WINO_STAMP(5);
-      __syncthreads();  // the store pass of block 0 has read its partial sums
+      if (GATE) lds_barrier();  // (the gate pass of block 0 has read its tile; its write-through stores drain meanwhile)
+      else __syncthreads();     // the store pass of block 0 has read its partial sums
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -898,6 +916,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
       }
     __syncthreads();
     if (m == 0) WINO_STAMP(4); else WINO_STAMP(6);
+    f32x4 gy[GATE ? 128 / PG : 1];   // GATE: this thread's rows of y2 (zero for rows past the batch)
+    if (GATE) {
+#pragma unroll
+      for (int q = 0; q < 128 / PG; ++q) gy[q] = zero4;
+    }
     if (col < d.Cout) {
 #pragma unroll
       for (int q = 0; q < 128 / PG; ++q) {
@@ -919,7 +942,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
           if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + img) * d.Cout + col);
           v = act_fwd4(v, d.out_act);
           if (!(dbg & 4) || v[0] == 12345.678f) store_wt4(yb + (size_t)p * d.Cout, v);
-          if (d.stats_mode == LVAE_STATS_BN_BWD) {
+          if (GATE) {
+            gy[q] = v;
+          } else if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
 #pragma unroll
@@ -937,9 +962,110 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
         }
       }
     }
+    if (GATE) {
+      constexpr int LDKG = 72, G_PLANE = 128 * LDKG, LDG = 132;   // bf16 row pitch of the y2 planes; float row pitch of the pre-activations
+      const size_t grow = (size_t)(n0 * d.H + oh0) * d.W + 128 * m;   // global pixel row of this block's row 0
+      const int prow0 = t / C4N;                                       // this thread's rows: prow0 + PG q
+      // gate weights of this wave (a-half column tile gwn, b-half tile 2 + gwn) and the residual rows: requested before the barriers
+      const int gwm = wave >> 1, gwn = wave & 1;
+      bf16x8 gqa[4][3], gqb[4][3];
+      {
+        const __bf16* gws = a.g_ws + lane * 8;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            gqa[s4][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s4 * 4 + gwn) * 3 + k) * 512);
+            gqb[s4][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s4 * 4 + 2 + gwn) * 3 + k) * 512);
+          }
+      }
+      f32x4 gres[128 / PG];
+#pragma unroll
+      for (int q = 0; q < 128 / PG; ++q) {
+        const int pl = prow0 + PG * q;
+        const bool okr = 128 * m + pl < nvalid;
+        gres[q] = (a.g_res != nullptr && okr) ? *reinterpret_cast<const f32x4*>(a.g_res + (grow + pl) * 64 + c4) : zero4;
+      }
+      lds_barrier();   // the store pass has read the partial sums: the area becomes the y2 planes [3][128][72] bf16
+      __bf16* Gs = reinterpret_cast<__bf16*>(smem);
+#pragma unroll
+      for (int q = 0; q < 128 / PG; ++q) {
+        bf16x4 pl3[3];
+        split4<3>(gy[q], pl3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x4*>(Gs + k * G_PLANE + (prow0 + PG * q) * LDKG + c4) = pl3[k];
+      }
+      lds_barrier();
+      f32x16 acca, accb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acca[r] = accb[r] = 0.f;
+      constexpr int GPA[6] = {2, 0, 1, 1, 0, 0}, GPB[6] = {0, 2, 1, 0, 1, 0};   // piece products in ascending order of magnitude
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) af[k] = *reinterpret_cast<const bf16x8*>(Gs + k * G_PLANE + (gwm * 32 + li) * LDKG + 16 * s4 + 8 * lh);
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+          acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[GPA[kk]], gqa[s4][GPB[kk]], acca, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[GPA[kk]], gqb[s4][GPB[kk]], accb, 0, 0, 0);
+        }
+      }
+      lds_barrier();   // the planes are dead: the area becomes the pre-activation tile [128][132] floats
+      float* Qs = smem;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = gwm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Qs[row * LDG + gwn * 32 + li] = acca[r];
+        Qs[row * LDG + 64 + gwn * 32 + li] = accb[r];
+      }
+      lds_barrier();
+      f32x4 gba = zero4, gbb = zero4, gpiv = zero4;
+      if (a.g_bias) {
+        gba = *reinterpret_cast<const f32x4*>(a.g_bias + c4);
+        gbb = *reinterpret_cast<const f32x4*>(a.g_bias + 64 + c4);
+      }
+      if (a.g_stats) gpiv = *reinterpret_cast<const f32x4*>(a.g_pivot + c4);
+#pragma unroll
+      for (int q = 0; q < 128 / PG; ++q) {
+        const int pl = prow0 + PG * q;
+        if (128 * m + pl < nvalid) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(Qs + pl * LDG + c4) + gba;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(Qs + pl * LDG + 64 + c4) + gbb;
+          if (a.g_ab) {
+            store_wt4(a.g_ab + (grow + pl) * 128 + c4, av);
+            store_wt4(a.g_ab + (grow + pl) * 128 + 64 + c4, bv);
+          }
+          f32x4 o = act_fwd4(av, a.g_act);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] *= sigmoidf_(bv[j]);
+          o += gres[q];
+          store_wt4(a.g_out + (grow + pl) * 64 + c4, o);
+          const f32x4 dl = o - gpiv;
+          st1 += dl;
+          st2 += dl * dl;
+        }
+      }
+    }
   }
   WINO_STAMP(7);
-  if (d.stats_out) {  // PG pixel groups x CW channels -> one row of partials per workgroup (fixed order)
+  float* const so = GATE ? a.g_stats : d.stats_out;
+  if (GATE && so != nullptr) {  // BatchNorm partials of `out` (the next block's first BatchNorm): one row per workgroup + the pivot row
+    __syncthreads();
+    float* red = smem;
+    *reinterpret_cast<f32x4*>(red + (t / C4N) * CW + c4) = st1;
+    *reinterpret_cast<f32x4*>(red + PG * CW + (t / C4N) * CW + c4) = st2;
+    __syncthreads();
+    if (t < 2 * CW) {
+      const int c = t % CW, which = t / CW;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < PG; ++r) v += red[which * PG * CW + r * CW + c];
+      so[((size_t)tm * 2 + which) * 64 + c] = v;
+      if (tm == 0 && which == 0) so[((size_t)(gridDim.x / a.ntn) * 2) * 64 + c] = a.g_pivot[c];
+    }
+  }
+  if (!GATE && d.stats_out) {  // PG pixel groups x CW channels -> one row of partials per workgroup (fixed order)
     __syncthreads();  // the partial sums are dead
     float* red = smem;
     *reinterpret_cast<f32x4*>(red + (t / C4N) * CW + c4) = st1;
@@ -1076,7 +1202,28 @@ int conv3x3_wino_stats_rows(const lvae_conv_desc* d) {
 }
 
 // -1000: not eligible. `workspace` must hold conv3x3_wino_workspace(d) bytes (the transformed weights).
+static int conv3x3_wino_launch(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, const lvae_rb_ext* gate, hipStream_t s);
+
 int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  return conv3x3_wino_launch(d, workspace, workspace_bytes, nullptr, s);
+}
+
+// rows of BatchNorm partials of `out` (= workgroups) when the 256-pixel six-product kernel can run `d` with the GateLayer2d fused behind it
+// (lvae_resblock_conv_f32, LVAE_RB_EPI_GATE, for shapes the whole-image kernels of resblock_img.hip do not take): 0 = it cannot
+int conv3x3_wino2_gate_rows(const lvae_conv_desc* d) {
+  if (d->workspace == nullptr || !al16w2(d->workspace) || !conv3x3_wino_eligible(d) || (size_t)d->workspace_bytes < conv3x3_wino_workspace(d)) return 0;
+  if (d->C1 != 64 || d->Cout != 64 || d->out_act != LVAE_ACT_NONE || d->gather != LVAE_GATHER_CONV) return 0;
+  WinoTile w;
+  if (!wino_tile(d, w) || w.mt != 2 || wino_lds_bytes(d, w) > 159 * 1024) return 0;
+  return ((d->N + w.NI - 1) / w.NI) * (d->H / w.TH);
+}
+
+int conv3x3_wino2_gate_try(const lvae_conv_desc* d, const lvae_rb_ext* gate, hipStream_t s) {
+  if (gate == nullptr || conv3x3_wino2_gate_rows(d) == 0) return -1000;
+  return conv3x3_wino_launch(d, d->workspace, (size_t)d->workspace_bytes, gate, s);
+}
+
+static int conv3x3_wino_launch(const lvae_conv_desc* d, void* workspace, size_t workspace_bytes, const lvae_rb_ext* gate, hipStream_t s) {
   if (workspace == nullptr || !conv3x3_wino_eligible(d)) return -1000;
   if (workspace_bytes < conv3x3_wino_workspace(d) || !al16w2(workspace)) return -1000;
   const int Cin = d->C1;
@@ -1117,13 +1264,29 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   a.d.in_fold = nullptr;
   a.store_pivot = folds && d->stats_out != nullptr && d->stats_mode == LVAE_STATS_BN_FWD;
+  a.g_ws = nullptr;
+  a.g_bias = a.g_res = a.g_pivot = nullptr;
+  a.g_ab = a.g_out = a.g_stats = nullptr;
+  a.g_act = 0;
+  if (gate != nullptr) {
+    if (mt != 2) return -1000;
+    a.g_ws = static_cast<const __bf16*>(gate->gate_ws);
+    a.g_bias = gate->gate_bias;
+    a.g_res = gate->res;
+    a.g_ab = gate->ab;
+    a.g_out = gate->out;
+    a.g_stats = gate->out_stats;
+    a.g_pivot = gate->out_stats_pivot;
+    a.g_act = gate->act;
+  }
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<128, 2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino_kernel<64, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -1140,7 +1303,8 @@ int conv3x3_wino_try(const lvae_conv_desc* d, void* workspace, size_t workspace_
   }
   const int img_groups = (d->N + NI - 1) / NI;
   const dim3 grid(img_groups * a.tiles_h * a.ntn);
-  if (mt == 2) hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(512), lds, s, a);
+  if (mt == 2 && gate != nullptr) hipLaunchKernelGGL(conv3x3_wino2_kernel<true>, grid, dim3(512), lds, s, a);
+  else if (mt == 2) hipLaunchKernelGGL(conv3x3_wino2_kernel<false>, grid, dim3(512), lds, s, a);
   else if (split) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, true>), grid, dim3(256), lds, s, a);
   else if (narrow) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 1, 1, false>), grid, dim3(256), lds, s, a);
   else if (kpad == 64) hipLaunchKernelGGL((conv3x3_wino_kernel<64, 2, 1, false>), grid, dim3(256), lds, s, a);

@@ -79,6 +79,12 @@ __device__ __forceinline__ void store_wt4(float* p, f32x4 v) {
 #endif
 }
 
+// LDS-only workgroup barrier. __syncthreads() is a workgroup FENCE, for which hipcc drains every outstanding memory operation of the wave
+// (s_waitcnt vmcnt(0)): global loads that were requested early on purpose, and write-through stores, whose acknowledgement takes a trip
+// to memory (1-2 us behind an epilogue's stores, measured with in-kernel stamps in resblock_img.hip). Where everything that crosses waves
+// goes through LDS, only the LDS counter has to drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
 

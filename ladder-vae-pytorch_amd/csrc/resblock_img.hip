@@ -705,6 +705,8 @@ int conv3x3_bf16_prepare_single(const lvae_conv_desc* d, int split, hipStream_t 
 size_t resblock_gate_ws_bytes(const lvae_conv_desc* d, int planes);
 void resblock_gate_prep_entry(const lvae_conv_desc* d, int planes, void* entry);
 int resblock_gate_prepare_single(const lvae_conv_desc* d, int planes, hipStream_t s);
+int conv3x3_wino2_gate_rows(const lvae_conv_desc* d);
+int conv3x3_wino2_gate_try(const lvae_conv_desc* d, const lvae_rb_ext* gate, hipStream_t s);
 
 // the 1x1 gate convolution in the direction it is used: 64 -> 128 (forward) or 128 -> 64 (backward)
 static bool rb_gate_ok(const lvae_conv_desc* g) {
@@ -822,6 +824,15 @@ extern "C" int lvae_resblock_gate_prepare_entry(const lvae_conv_desc* g, void* e
   return 0;
 }
 
+// rows of out_stats (= workgroups) of an LVAE_RB_EPI_GATE launch for d: the whole-image kernels' rows, or — fp32, 64 -> 64 channels, the
+// 256-pixel six-product Winograd kernel's shapes (16x16 and 32x32 levels at batch 256) with ITS workspace attached — that kernel's rows
+extern "C" int32_t lvae_resblock_conv_gate_rows(const lvae_conv_desc* d) {
+  RbArgs a;
+  int mi;
+  if (rb_plan(d, a, mi)) return a.nwg;
+  return d != nullptr && d->precision == LVAE_PREC_F32 ? conv3x3_wino2_gate_rows(d) : 0;
+}
+
 extern "C" int32_t lvae_resblock_conv_rows(const lvae_conv_desc* d) {
   RbArgs a;
   int mi;
@@ -849,8 +860,30 @@ extern "C" int lvae_resblock_conv_f32(const lvae_conv_desc* d, const lvae_rb_ext
   LVAE_REQUIRE(d != nullptr && d->w != nullptr && d->y != nullptr, LVAE_EINVAL, "lvae_resblock_conv_f32: null descriptor / w / y");
   RbArgs a;
   int mi = 1;
-  LVAE_REQUIRE(rb_plan(d, a, mi), LVAE_EINVAL,
-               "lvae_resblock_conv_f32: shape not supported (3x3 / stride 1 / pad 1, 64 -> 64 channels, H*W a divisor of 64, fp32 tensors)");
+  if (!rb_plan(d, a, mi)) {
+    // larger levels: only conv + gate (forward), through the 256-pixel six-product Winograd kernel with the gate behind it
+    LVAE_REQUIRE(ext != nullptr && ext->prologue == LVAE_RB_PRO_AFFINE && ext->epilogue == LVAE_RB_EPI_GATE && d->precision == LVAE_PREC_F32 &&
+                     conv3x3_wino2_gate_rows(d) > 0,
+                 LVAE_EINVAL,
+                 "lvae_resblock_conv_f32: shape not supported (whole-image kernels: 3x3 / stride 1 / pad 1, 64 -> 64 channels, H*W a divisor of 64, "
+                 "fp32 tensors; conv + gate also for lvae_resblock_conv_gate_rows(d) > 0)");
+    const lvae_rb_ext& e = *ext;
+    LVAE_REQUIRE(e.out && al16r(e.out) && al16r(e.ab) && al16r(e.res) && al16r(e.gate_bias) && al16r(e.out_stats) && al16r(e.out_stats_pivot) &&
+                     (e.out_stats == nullptr || e.out_stats_pivot != nullptr) && d->stats_out == nullptr && d->x != nullptr && d->y != nullptr,
+                 LVAE_EINVAL, "lvae_resblock_conv_f32: gate epilogue needs x, y, out (16-byte aligned tensors); statistics of y are not available with it");
+    lvae_conv_desc g = lvae_conv_desc{};
+    g.w = e.gate_w; g.w_sk = e.gate_w_sk; g.w_sn = e.gate_w_sn; g.precision = d->precision; g.C1 = 64; g.Cout = 128;
+    g.workspace = e.gate_ws; g.workspace_bytes = e.gate_ws_bytes;
+    LVAE_REQUIRE(e.gate_ws != nullptr && al16r(e.gate_ws) && (size_t)e.gate_ws_bytes >= resblock_gate_ws_bytes(&g, 3) && (e.gate_ws_ready || e.gate_w != nullptr),
+                 LVAE_EWORKSPACE, "lvae_resblock_conv_f32: gate_ws missing or smaller than lvae_resblock_gate_workspace(), or not ready and no gate_w");
+    if (!e.gate_ws_ready) {
+      const int rc = resblock_gate_prepare_single(&g, 3, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    const int rc = conv3x3_wino2_gate_try(d, ext, (hipStream_t)stream);
+    LVAE_REQUIRE(rc != -1000, LVAE_EINVAL, "lvae_resblock_conv_f32: the Winograd kernel did not take the descriptor");
+    return rc;
+  }
   const int split = rb_split(d);
   a.e = lvae_rb_ext{};
   if (ext != nullptr) a.e = *ext;

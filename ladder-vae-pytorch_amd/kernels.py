@@ -448,6 +448,7 @@ def rb_rows(x, weight, g):
 import os as _os
 _RB_FWD_MIN_HW = int(_os.environ.get('LVAE_RB_FWD_MIN_HW', '16'))
 _RB_BWD_MIN_HW = int(_os.environ.get('LVAE_RB_BWD_MIN_HW', '1'))
+_RB_GATE_LARGE = _os.environ.get('LVAE_RB_GATE_LARGE', '1') != '0'   # conv2 + gate in one launch at the >= 16x16 levels (Winograd kernel)
 
 
 def rb_policy(x, weight, g):
@@ -458,13 +459,13 @@ def rb_policy(x, weight, g):
     return (_RB_FWD_MIN_HW > 0 and hw >= _RB_FWD_MIN_HW), (_RB_BWD_MIN_HW > 0 and hw >= _RB_BWD_MIN_HW)
 
 
-def _rb_in_bn(d, in_bn, x):
-    """Training-mode BatchNorm of the convolution input from partial sums: folded into the prologue when the producer stored its pivot,
-    by lvae_bn_finalize_parts_f32 otherwise. Returns (coef 4-tuple, keep-alive)."""
+def _rb_in_bn(d, in_bn, x, can_fold=True):
+    """Training-mode BatchNorm of the convolution input from partial sums: folded into the prologue when the producer stored its pivot
+    (and the kernel that will run can fold), by lvae_bn_finalize_parts_f32 otherwise. Returns (coef 4-tuple, keep-alive)."""
     sp, pivot, bn = in_bn
     N, H, W, C1 = x.shape
     M = N * H * W
-    if sp.has_pivot:
+    if sp.has_pivot and can_fold:
         coef = torch.empty((4, C1), dtype=torch.float32, device=x.device)
         fold = BnFold(ptr(sp.buf), sp.rows, M, ptr(bn.weight), ptr(bn.bias), bn.eps, bn.momentum, ptr(bn.running_mean),
                       ptr(bn.running_var), ptr(coef))
@@ -517,6 +518,20 @@ def rb_conv(x, weight, g, bias, in_act, out_scale, in_bn=None, coef=None, stats_
     return y, parts, coef
 
 
+def rb_gate_rows(x, weight, g):
+    """Workgroups (= statistics rows of `out`) of the forward conv + gate fusion for the 3x3 convolution (weight, g) on x: the whole-image
+    kernels' shapes, or the 256-pixel six-product Winograd kernel's (fp32, 16x16 and 32x32 levels at batch 256). 0: not available."""
+    if _ddi is not None or x.dtype != torch.float32 or x.dim() != 4 or g.transposed or g.KH != 3 or g.stride != 1 or g.pad != 1:
+        return 0
+    N, H, W, _ = x.shape
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV)
+    rows = int(_C.load().lvae_resblock_conv_rows(C.byref(d)))
+    if rows > 0:
+        return rows
+    _conv_ws(d, weight, x.device)   # the Winograd kernel's transformed weights: the buffer the plain convolution of this layer uses too
+    return int(_C.load().lvae_resblock_conv_gate_rows(C.byref(d)))
+
+
 def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bias, res, act, in_bn=None, coef=None, stats_pivot=None):
     """Second half of a gated residual block in one launch: y2 = (conv3x3(act(BN(x))) + bias) * out_scale, ab = conv1x1(y2) + gate_bias,
     out = act(a) * sigmoid(b) + res, BatchNorm partials of out around stats_pivot. Returns (y2, ab, out, StatParts | None, coef)."""
@@ -525,10 +540,14 @@ def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bia
     y = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=dev)
     ab = torch.empty((N, H, W, gate_g.Cout), dtype=torch.float32, device=dev)
     out = torch.empty((N, H, W, gate_g.Cout // 2), dtype=torch.float32, device=dev)
-    d, _ = _rb_desc(x, weight, g, False, y, bias, None, None, in_act, out_scale)
+    d, need = _rb_desc(x, weight, g, False, y, bias, None, None, in_act, out_scale)
+    can_fold = True
+    if not need:   # not a whole-image shape: the Winograd kernel with the gate behind it (its own transformed weights)
+        _conv_ws(d, weight, dev)
+        can_fold = bool(_C.load().lvae_conv2d_folds_bn_finalize(C.byref(d)))
     keep = None
     if in_bn is not None:
-        coef, keep = _rb_in_bn(d, in_bn, x)
+        coef, keep = _rb_in_bn(d, in_bn, x, can_fold)
     else:
         d.in_scale, d.in_shift = ptr(coef[0]), ptr(coef[1])
     e = RbExt()
@@ -538,7 +557,7 @@ def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bia
     e.res, e.ab, e.out = ptr(res), ptr(ab), ptr(out)
     parts = None
     if stats_pivot is not None:
-        rows = _C.load().lvae_resblock_conv_rows(C.byref(d))
+        rows = _C.load().lvae_resblock_conv_gate_rows(C.byref(d))
         buf = torch.empty((rows + 1, 2, g.Cout), dtype=torch.float32, device=dev)
         parts = StatParts(buf, rows, True)
         e.out_stats, e.out_stats_pivot = ptr(buf), ptr(stats_pivot)

@@ -187,9 +187,26 @@ class ResBlockFn(Function):
             return ResBlockFn._forward_fused(ctx, x, blk, m1, m2, parts, pivot_in, rb_bwd)
         s16 = (not rb_bwd and blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
                (training or not torch.is_grad_enabled()) and K.resblock_bf16_storage(x, blk.conv1.weight, blk.conv1.geom()))
+        # larger levels (fp32): conv2 and the gate in ONE launch (the gate behind the Winograd kernel's epilogue, conv3x3_wino.hip)
+        fuse_gate = bool(full and not s16 and K._RB_GATE_LARGE and K.rb_gate_rows(x, blk.conv2.weight, blk.conv2.geom()) > 0)
+        fused_out = None
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
             want_stats = training and nxt is not None and nxt.running_mean is not None
+            if i == 1 and fuse_gate:
+                in_bn = coef = None
+                if parts is not None:
+                    in_bn = (parts, bn.running_mean, bn)
+                else:
+                    coef = K.bn_stats(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+                pivot = st[0][3].detach() if (st[0][3] is not None and _GATE_STATS) else None
+                gate = blk.gate
+                y, ab_f, out_f, oparts_f, (sc, sh, mean, rstd) = K.rb_conv_gate(
+                    h, cv.weight, cv.geom(), cv.bias, act, m, gate.weight, gate.geom(), gate.bias, x, act, in_bn=in_bn, coef=coef, stats_pivot=pivot)
+                fused_out = (ab_f, out_f, oparts_f, pivot)
+                st.append((h, sc, sh, mean, rstd))
+                h = y
+                continue
             if bn is not None and training and parts is not None:
                 # statistics of h exist as partial sums: finalized inside the convolution where the kernel can (<= 4x4 levels)
                 y, parts_out, (sc, sh, mean, rstd) = K.conv2d(
@@ -217,7 +234,11 @@ class ResBlockFn(Function):
         y2 = h
         ab = None
         blk.__dict__['_out_parts'] = None
-        if blk.gate is not None:
+        if fused_out is not None:
+            ab, out, oparts, pivot = fused_out
+            if oparts is not None:
+                blk.__dict__['_out_parts'] = (oparts, pivot)
+        elif blk.gate is not None:
             if training and blk.bn1 is not None and blk.bn1.running_mean is not None and _GATE_STATS:
                 # the block output is (usually) the next block's BatchNorm input: statistics in the gate kernel's epilogue, around
                 # this block's own running mean (same residual stream: a pivot inside the data range); the copy keeps the pivot

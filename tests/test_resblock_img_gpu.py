@@ -158,3 +158,49 @@ def test_fused_block_shape_gate(K):
     w32 = mk(64, 32, 3)
     assert K.rb_rows(torch.zeros(5, 4, 4, 32, device='cuda'), w32, K.ConvGeom(w32, 1, 1)) == 0
     assert K.rb_rows(torch.zeros(5, 4, 4, 64, device='cuda'), w, K.ConvGeom(w, 2, 1)) == 0
+
+
+@pytest.mark.parametrize('shape', [(256, 16, 16), (300, 16, 16), (64, 32, 32), (70, 32, 32)])
+def test_conv_gate_fusion_behind_the_winograd_kernel(K, shape):
+    """lvae_resblock_conv_f32 / LVAE_RB_EPI_GATE at the >= 16x16 levels (fp32): the GateLayer2d and the residual add run behind the 256-pixel
+    six-product Winograd kernel's epilogue. y2, ab, out, the folded BatchNorm finalize of the input and the BatchNorm partials of `out`
+    against the float64 statement of lib/nn.py:80-99,118-126."""
+    N, H, W = shape
+    C = 64
+    p = make_block(N, H, W, N + 3 * H)
+    o = reference(p)
+    dev = 'cuda'
+    f = lambda t: t.detach().float().to(dev)
+    x = nhwc(p.x.detach())
+    w1, w2, wg = packed_weight(p.w1.detach()), packed_weight(p.w2.detach()), packed_weight(p.wg.detach())
+    ge1, ge2, geg = K.ConvGeom(w1, 1, 1), K.ConvGeom(w2, 1, 1), K.ConvGeom(wg, 1, 0)
+    assert K.rb_rows(x, w2, ge2) == 0 and K.rb_gate_rows(x, w2, ge2) > 0
+    mk_bn = lambda ga, be: types.SimpleNamespace(weight=f(ga), bias=f(be), running_mean=torch.zeros(C, device=dev),
+                                                 running_var=torch.ones(C, device=dev), eps=1e-5, momentum=0.1)
+    bn1, bn2 = mk_bn(p.g1, p.be1), mk_bn(p.g2, p.be2)
+    m1, m2 = p.m1.float().to(dev), p.m2.float().to(dev)
+    coef1 = K.bn_stats(x, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
+    y1, parts2 = K.conv2d(x, w1, ge1, bias=f(p.b1), in_scale=coef1[0], in_shift=coef1[1], in_act='elu', out_scale=m1, stats_pivot=bn2.running_mean)
+    assert parts2 is not None
+    pivot = coef1[2]
+    y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, w2, ge2, f(p.b2), 'elu', m2, wg, geg, f(p.bg), x, 'elu',
+                                                in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot)
+    torch.cuda.synchronize()
+    assert rel(nchw(y1), o.y1.detach()) < 3e-6
+    assert rel(nchw(y2), o.y2.detach()) < 4e-6
+    assert rel(nchw(ab), o.ab.detach()) < 4e-6
+    assert rel(nchw(out), o.out.detach()) < 4e-6
+    y1r = o.y1.detach()
+    mean2, var2 = y1r.mean((0, 2, 3)), y1r.var((0, 2, 3), unbiased=False)
+    torch.testing.assert_close(coef2[2].cpu().double(), mean2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(coef2[3].cpu().double(), 1 / torch.sqrt(var2 + 1e-5), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn2.running_mean.cpu().double(), 0.1 * mean2, rtol=1e-5, atol=1e-5)
+    s = oparts.rows_view().double().sum(0).cpu()
+    dl = o.out.detach() - pivot.cpu().double().view(1, -1, 1, 1)
+    torch.testing.assert_close(s[0], dl.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(s[1], (dl * dl).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    assert torch.equal(oparts.buf[oparts.rows, 0], pivot)
+    # the same launch with given coefficients (no partial sums: e.g. the first block behind a resampling convolution)
+    y2b, abb, outb, _, _ = K.rb_conv_gate(y1, w2, ge2, f(p.b2), 'elu', m2, wg, geg, f(p.bg), x, 'elu', coef=coef2, stats_pivot=None)
+    torch.cuda.synchronize()
+    assert torch.equal(y2b, y2) and torch.equal(abb, ab) and torch.equal(outb, out)
