@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     f32x4 xv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) xv[q] = *reinterpret_cast<const f32x4*>(d.x + grow[q] * 64 + c4);
+    zero_ring();   // while the loads are in flight (the patch region is free from the start in this prologue)
     f32x4 sc = one4, sh = zero4;
     if (f.parts != nullptr) {
       // everything thread c needs after the reduction is requested beside the partial rows, not behind the barrier
@@ -337,7 +338,6 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       put_interior(q, ok[q] ? v : zero4);
     }
     RB_STAMP(10);
-    zero_ring();
     RB_STAMP(11);
   }
 
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       xv[q] = *reinterpret_cast<const f32x4*>(e.bwd_x + grow[q] * 64 + c4);
       dm[q] = e.pro_drop ? *reinterpret_cast<const f32x4*>(e.pro_drop + (size_t)img_n[q] * 64 + c4) : one4;
     }
+    zero_ring();   // while the loads are in flight
     const f32x4 sc = *reinterpret_cast<const f32x4*>(e.bwd_coef + c4), sh = *reinterpret_cast<const f32x4*>(e.bwd_coef + 64 + c4);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(e.bwd_coef + 128 + c4), rs = *reinterpret_cast<const f32x4*>(e.bwd_coef + 192 + c4);
     const bool acc_here = bid == 0 && t < 64;
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       if (ok[q] && e.xt_out) store_wt4(e.xt_out + grow[q] * 64 + c4, v);
       put_interior(q, v);
     }
-    zero_ring();
   }
 
   if (PRO == LVAE_RB_PRO_GATE_BWD) {

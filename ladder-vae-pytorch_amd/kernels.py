@@ -532,7 +532,8 @@ def rb_gate_rows(x, weight, g):
     return int(_C.load().lvae_resblock_conv_gate_rows(C.byref(d)))
 
 
-def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bias, res, act, in_bn=None, coef=None, stats_pivot=None):
+def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bias, res, act, in_bn=None, coef=None, stats_pivot=None,
+                 prefetch=None):
     """Second half of a gated residual block in one launch: y2 = (conv3x3(act(BN(x))) + bias) * out_scale, ab = conv1x1(y2) + gate_bias,
     out = act(a) * sigmoid(b) + res, BatchNorm partials of out around stats_pivot. Returns (y2, ab, out, StatParts | None, coef)."""
     N, H, W, _ = x.shape
@@ -561,6 +562,7 @@ def rb_conv_gate(x, weight, g, bias, in_act, out_scale, gate_w, gate_g, gate_bia
         buf = torch.empty((rows + 1, 2, g.Cout), dtype=torch.float32, device=dev)
         parts = StatParts(buf, rows, True)
         e.out_stats, e.out_stats_pivot = ptr(buf), ptr(stats_pivot)
+    _rb_prefetch(e, prefetch)
     call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
     del keep
     return y, ab, out, parts, coef
@@ -596,7 +598,7 @@ def rb_gate_dgrad(dout, ab, gate_w, gate_g, act, drop, weight, g, bn_bwd, prefet
     return dab, dy2, dh, parts
 
 
-def rb_apply_dgrad(parts_in, dh_in, x_bn, coef0, act, dgamma, dbeta, drop, weight, g, bn_bwd):
+def rb_apply_dgrad(parts_in, dh_in, x_bn, coef0, act, dgamma, dbeta, drop, weight, g, bn_bwd, prefetch=None):
     """BatchNorm backward (training mode; parts_in = the sums the producer of dh_in left) + Dropout2d mask + dgrad of the block's first
     convolution in one launch: dy1 = BN'(dh_in; x_bn) * drop, dh1 = dgrad3x3(dy1) with the sums of bn_bwd = (x, coef block row 0, act).
     coef0: row 0 of the (4, C) coefficient block of the BatchNorm being differentiated. Returns (dy1, dh1, parts)."""
@@ -610,6 +612,7 @@ def rb_apply_dgrad(parts_in, dh_in, x_bn, coef0, act, dgamma, dbeta, drop, weigh
     e.bwd_parts, e.bwd_rows, e.bwd_act, e.bwd_M = ptr(parts_in), parts_in.shape[0], ACT[act], N * H * W
     e.bwd_coef, e.bwd_x, e.dgamma, e.dbeta, e.pro_drop, e.xt_out = ptr(coef0), ptr(x_bn), ptr(dgamma), ptr(dbeta), ptr(drop), ptr(dy1)
     parts = _rb_bn_bwd(d, bn_bwd, dh)
+    _rb_prefetch(e, prefetch)
     call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
     return dy1, dh, parts
 

@@ -155,6 +155,30 @@ def conv(x, mod, x2=None, out_act=None):
 _GATE_STATS = os.environ.get('LVAE_NO_GATE_STATS') is None  # A/B switch, profiling only
 
 
+# The fused blocks of the low-resolution levels run as one dependent chain, and every launch streams weights of its own that are cold in
+# the L2s. Inside a block the first launch warms the L2s for the second (kernels.rb_weight_ranges); ACROSS blocks the order is only known
+# from the previous step: each block remembers which fused block ran right after it (per direction) and what that block's first launch
+# streams. Speed only: a stale link makes a launch touch bytes nobody needs (the buffers stay alive as long as their weights do).
+import weakref as _weakref
+
+_rb_chain = {'fwd': None, 'bwd': None}
+
+
+def _rb_link(direction, blk, first_ranges):
+    blk.__dict__['_rb_first_' + direction] = first_ranges
+    prev = _rb_chain[direction]
+    prev = prev() if prev is not None else None
+    if prev is not None and prev is not blk:
+        prev.__dict__['_rb_next_' + direction] = _weakref.ref(blk)
+    _rb_chain[direction] = _weakref.ref(blk)
+
+
+def _rb_next_ranges(direction, blk):
+    nb = blk.__dict__.get('_rb_next_' + direction)
+    nb = nb() if nb is not None else None
+    return nb.__dict__.get('_rb_first_' + direction) if nb is not None else None
+
+
 class ResBlockFn(Function):
     """Whole pre-activation residual block ('bacdbacd' / 'bacdbac' recipes of lib/nn.py:64-89, with or without
     BatchNorm, Dropout2d and the gate) as ONE autograd node:
@@ -188,7 +212,8 @@ class ResBlockFn(Function):
         s16 = (not rb_bwd and blk.gate is not None and blk.bn1 is not None and blk.bn2 is not None and blk.gate.bias is not None and
                (training or not torch.is_grad_enabled()) and K.resblock_bf16_storage(x, blk.conv1.weight, blk.conv1.geom()))
         # larger levels (fp32): conv2 and the gate in ONE launch (the gate behind the Winograd kernel's epilogue, conv3x3_wino.hip)
-        fuse_gate = bool(full and not s16 and K._RB_GATE_LARGE and K.rb_gate_rows(x, blk.conv2.weight, blk.conv2.geom()) > 0)
+        fuse_gate = bool(full and not s16 and K._RB_GATE_LARGE and K.rb_rows(x, blk.conv2.weight, blk.conv2.geom()) == 0 and
+                         K.rb_gate_rows(x, blk.conv2.weight, blk.conv2.geom()) > 0)   # (whole-image shapes follow rb_policy above)
         fused_out = None
         for i, (bn, cv, m) in enumerate(((blk.bn1, blk.conv1, m1), (blk.bn2, blk.conv2, m2))):
             nxt = blk.bn2 if i == 0 else None  # conv1's output is BatchNorm 2's input: statistics in conv1's epilogue
@@ -271,13 +296,15 @@ class ResBlockFn(Function):
                                         bn1.eps, bn1.momentum)
         else:
             coef1 = K.bn_stats(x, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
+        _rb_link('fwd', blk, K.rb_weight_ranges(x, cv1.weight, cv1.geom(), False))
         nxt = K.rb_weight_ranges(x, cv2.weight, cv2.geom(), False, gate=(gate.weight, gate.geom()))   # what the second launch will stream
         y1, parts2, coef1 = K.rb_conv(x, cv1.weight, cv1.geom(), cv1.bias, act, m1, in_bn=in_bn, coef=coef1, stats_pivot=bn2.running_mean,
                                       prefetch=nxt)
         blk.__dict__['_out_parts'] = None
         pivot = coef1[2].detach() if _GATE_STATS else None   # this block's own batch mean: inside the data range of the residual stream
         y2, ab, out, oparts, coef2 = K.rb_conv_gate(y1, cv2.weight, cv2.geom(), cv2.bias, act, m2, gate.weight, gate.geom(), gate.bias, x, act,
-                                                    in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot)
+                                                    in_bn=(parts2, bn2.running_mean, bn2), stats_pivot=pivot,
+                                                    prefetch=_rb_next_ranges('fwd', blk))
         if oparts is not None:
             blk.__dict__['_out_parts'] = (oparts, pivot)
         ctx.blk, ctx.training, ctx.s16 = blk, True, False
@@ -297,13 +324,14 @@ class ResBlockFn(Function):
             # low-resolution levels: gate backward + dgrad conv2, then BatchNorm-2 backward + dgrad conv1, then the BatchNorm-1 apply
             gate, w2, w1, bn2, bn1 = blk.gate, blk.conv2.weight, blk.conv1.weight, blk.bn2, blk.bn1
             gw = gate.weight
+            _rb_link('bwd', blk, K.rb_weight_ranges(dout, w2, blk.conv2.geom(), True, gate=(gw, gate.geom()), gate_bwd=True))
             dab, dy2, dh2, parts2 = K.rb_gate_dgrad(dout, ab, gw, gate.geom(), act, m2, w2, blk.conv2.geom(), bn_bwd=(y1, sc2, act),
                                                     prefetch=K.rb_weight_ranges(dout, w1, blk.conv1.geom(), True))
             if gw.requires_grad:
                 wgrad(y2, dab, gw, gate.geom(), grad_buf(gw), grad_buf(gate.bias))
             wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2, in_act=act)
             dy1, dh1, parts1 = K.rb_apply_dgrad(parts2, dh2, y1, sc2, act, grad_buf(bn2.weight), grad_buf(bn2.bias), m1, w1, blk.conv1.geom(),
-                                                bn_bwd=(x, sc1, act))
+                                                bn_bwd=(x, sc1, act), prefetch=_rb_next_ranges('bwd', blk))
             wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
             dx = K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias), add=dout)
             return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)

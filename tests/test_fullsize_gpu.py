@@ -144,6 +144,9 @@ def test_bf16_training_step_is_within_the_stated_tolerance_of_the_fp32_oracle(ca
     assert rec['kl']['rel'] <= 5e-2, rec['kl']                # KL is the small difference of large terms
     assert rec['gradnorm']['rel'] <= 5e-2, rec['gradnorm']
     assert rec['grad_worst_rel_l2'] > 1e-4                      # ... and it really ran in reduced precision
+    # no single gradient tensor drifts further than bf16 storage + bf16 operands explain (measured: 1.6e-2 cfg3, 1.8e-2 cfg5, round 3):
+    # a storage or fusion change that moves this silently is a regression
+    assert rec['grad_worst_rel_l2'] <= 3e-2, (rec['grad_worst_key'], rec['grad_worst_rel_l2'])
 
 
 def test_celeba20_shard_step_at_its_real_per_gpu_batch():
