@@ -943,6 +943,11 @@ static bool bfwg_plan(const lvae_conv_desc* d, BfWgArgs& a) {
   if (!al16b(d->x) || !al16b(d->in_scale) || !al16b(d->in_shift)) return false;
   const int64_t M = (int64_t)d->N * d->H * d->W;
   if (M < 256 * 64 || M * 64 >= ((int64_t)1 << 31)) return false;
+  // Layers of exactly 16 k pixels with fp32-stored operands (the 8x8 level at batch 256, whose blocks run the fused whole-image launches with
+  // fp32 storage) keep the grouped fp32 Winograd weight gradient: twelve gradients per launch at 9.7 + 2.9 us each (measured in the fp32 step)
+  // against 14.1 + 8.3 us for one launch + one slab reduce per gradient here. bf16-stored operands still need this kernel.
+  static const int64_t min_m_f32 = tune("LVAE_BF16_WGRAD_MIN_M", 256 * 64 + 1);
+  if (M < min_m_f32 && d->x_dtype != LVAE_DT_BF16 && d->y_dtype != LVAE_DT_BF16) return false;
   BfArgs g;
   int bm = 128;
   if (!bf_plan_bm(d, 1, 128, g) || g.halo_px > 224 || (g.NI * g.TH * g.TW) % 16 != 0 ||
