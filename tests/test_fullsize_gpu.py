@@ -109,13 +109,17 @@ def run_engine(case, use_graph, dtype='f32'):
     rec['grad_worst_key'] = worst_key
     rec['gradnorm'] = {'hip': gsq ** 0.5, 'oracle': ref_sq ** 0.5, 'rel': abs(gsq ** 0.5 - ref_sq ** 0.5) / ref_sq ** 0.5}
     _report['%s/%s' % (case, rec['mode'])] = rec
+    _dump_report()
+    return rec
+
+
+def _dump_report():
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'fullsize_parity.json'), 'w') as f:
             json.dump(_report, f, indent=1)
     except OSError:
         pass
-    return rec
 
 
 @pytest.mark.parametrize('use_graph', [False, True], ids=['eager', 'graph'])
@@ -198,6 +202,7 @@ def test_celeba20_shard_step_at_its_real_per_gpu_batch():
         assert abs(a - b) <= 1e-2 * abs(a), (k, a, b)
     assert abs(res['f32-graph']['gradnorm'] - res['bf16-graph']['gradnorm']) <= 5e-2 * res['f32-graph']['gradnorm']
     _report['cfg5_celeba20_b128/properties'] = res
+    _dump_report()
 
 
 def test_iw_1000_sample_evaluation_on_the_64x64_20_layer_model():
