@@ -542,6 +542,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
+    if allreduce is not None:
+        torch.cuda.synchronize()
+        allreduce.close()   # lvae_allreduce_destroy: the private RCCL communicator goes before the process group does
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

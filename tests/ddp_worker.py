@@ -74,6 +74,7 @@ def main():
         torch.cuda.synchronize()
         assert step.graph_a is not None and step.graph_b is None      # ONE graph: backward, exchange and Adamax together
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'launched': ar.launched})
+        ar.close()
         torch.distributed.destroy_process_group()
     elif mode == 'rccl1_fallback':
         # a collective that refuses to be captured: TrainStep's capture probe finds out before the step is captured and the same process
