@@ -15,6 +15,15 @@
 
 namespace lvae {
 
+// device copy of the out-of-place rehearsal form: a KERNEL, not hipMemcpyAsync — a memcpy NODE on a side branch of a captured graph was
+// suspected of the 0.57 ms each bucket cost in the one-rank rehearsal (tools/forced_ab.sh); n % 4 == 0 or the tail is copied by scalars
+__global__ __launch_bounds__(256) void allreduce_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+
 struct RcclId {
   char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
 };
@@ -125,7 +134,12 @@ extern "C" int lvae_allreduce_enqueue(void* handle, float* buf, int64_t n, float
     // out of place + copy back: with ONE rank an in-place all-reduce enqueues nothing at all, so a single-GPU rehearsal of the captured
     // exchange would capture an empty branch; this form always puts RCCL's kernel (its copy, for one rank) and a device copy on the stream
     LVAE_RCCL_CHECK(h->api, h->api.AllReduce(buf, scratch, (size_t)n, 7 /* ncclFloat32 */, 0 /* ncclSum */, h->comm, ss), "ncclAllReduce");
-    LVAE_HIP_CHECK(hipMemcpyAsync(buf, scratch, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, ss), "lvae_allreduce_enqueue: hipMemcpyAsync");
+    if ((reinterpret_cast<uintptr_t>(buf) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
+      hipLaunchKernelGGL(allreduce_copy_kernel, dim3(grid_for(n >> 2, 256, 1024)), dim3(256), 0, ss, scratch, buf, n);
+      LVAE_LAUNCH_CHECK("allreduce_copy");
+    } else {
+      LVAE_HIP_CHECK(hipMemcpyAsync(buf, scratch, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, ss), "lvae_allreduce_enqueue: hipMemcpyAsync");
+    }
   } else {
     LVAE_RCCL_CHECK(h->api, h->api.AllReduce(buf, buf, (size_t)n, 7, 0, h->comm, ss), "ncclAllReduce");
   }

@@ -77,8 +77,17 @@ class GradAllReduce:
     """
 
     def __init__(self, flat_grads, group=None, bucket_mb=None, segments=None):
+        # Which form the exchange takes. On the GPU with a capturable backend (RCCL) the default is 'split': the whole arena as ONE message
+        # after backward, between the fwd+bwd graph and the Adamax graph. Measured on MI355X (tools/forced_ab.sh): a
+        # side branch of a captured graph does not run beside the main branch on this platform — every bucket with real work on it added its
+        # full duration (+0.55 ms per 8 MB bucket in the one-rank rehearsal, +4.3 ms for 7 buckets) on top of +0.86 ms for the fork / join
+        # edges alone, while the split form costs +0.07 ms. LVAE_DDP_MODE=overlap selects the in-graph overlapped form (completion-ordered
+        # buckets on the side stream during backward); eager launches (gloo, CPU) keep it as their default: eager streams do overlap.
+        on_gpu_capturable = flat_grads.is_cuda and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        self.mode = os.environ.get('LVAE_DDP_MODE', 'split' if on_gpu_capturable else 'overlap')
         if bucket_mb is None:
-            bucket_mb = float(os.environ.get('LVAE_BUCKET_MB', '8'))   # tuning switch (xGMI rings are per-link bound: see DESIGN.md §6)
+            # overlap: 8 MB buckets (xGMI rings are per-link bound; the count was free in round 2's sweep); split: one message
+            bucket_mb = float(os.environ.get('LVAE_BUCKET_MB', '8' if self.mode != 'split' else '1048576'))
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -99,7 +108,7 @@ class GradAllReduce:
         self.capturable = dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.stream = torch.cuda.Stream(device=flat_grads.device) if self.on_gpu else None
         self.scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat_grads.device)
-        self.overlap = segments is not None and os.environ.get('LVAE_DDP_MODE', 'overlap') != 'split'
+        self.overlap = segments is not None and self.mode != 'split'
         self.next_bucket = 0
         self.launched = []          # bucket indices in launch order of the current step (tests look at it)
         # Buckets on the GPU go through a communicator of our own (rccl.Comm): its ncclAllReduce is a plain launch on our side stream,
@@ -120,7 +129,7 @@ class GradAllReduce:
                 self.comm, self.comm_error = None, 'another rank has no private communicator'
         # one-rank rehearsal (LVAE_FORCE_DIST=1): the out-of-place form, so that the captured exchange holds real RCCL / copy nodes
         self.scratch = None
-        if self.comm is not None and self.world == 1:
+        if self.comm is not None and self.world == 1 and os.environ.get('LVAE_FORCE_INPLACE') != '1':   # (diagnosis: the in-place no-op form)
             self.scratch = torch.empty(max(hi - lo for lo, hi, _ in self.buckets), dtype=torch.float32, device=flat_grads.device)
 
     def capture_probe(self):

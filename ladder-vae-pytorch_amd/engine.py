@@ -156,7 +156,8 @@ class TrainStep:
             where = 'inside the step graph' if self.use_graph else 'eager launches'
             return '%d completion-ordered buckets on a side stream during backward, %s' % (len(ar.buckets), where)
         why = ' (fallback: %s)' % self.fallback_reason if getattr(self, 'fallback_reason', None) else ''
-        return '%d buckets after backward, outside the step graph (split)%s' % (len(ar.buckets), why)
+        return ('%d bucket(s) after backward on the side stream, between the fwd+bwd graph and the Adamax graph (split: side branches of a '
+                'captured graph do not overlap on this platform, DESIGN.md §6)%s' % (len(ar.buckets), why))
 
     def _traced_split_step(self):
         ts = [time.perf_counter()]

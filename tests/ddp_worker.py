@@ -1,8 +1,10 @@
 """Worker process of the data-parallel GPU tests (tests/test_ddp_gpu.py starts it; not collected by pytest).
 
   single  one rank, no process group: TrainStep (hipGraph), the reference point
-  rccl1   one rank over RCCL with LVAE_FORCE_DIST=1: the N > 1 code path — completion-ordered buckets exchanged on the side stream
-          while backward runs, all inside the captured graph
+  rccl1_split  one rank over RCCL with LVAE_FORCE_DIST=1, the DEFAULT form of a multi-rank GPU run: one message after backward, outside the
+          graphs (fwd+bwd graph | exchange on the side stream | Adamax graph)
+  rccl1   the same with LVAE_DDP_MODE=overlap: completion-ordered buckets exchanged on the side stream while backward runs, all inside the
+          captured graph
   rccl1_fallback  as rccl1, but the all-reduce refuses to be captured: TrainStep must fall back to the split form in the same process
   gloo2   rank RANK of 2 over gloo, both ranks on the one GPU of the test box, eager launches (gloo cannot be captured)
   gloo2a  the same with every weight-gradient kernel on one of two side streams (async_wgrad): a bucket's exchange must wait for them
@@ -57,8 +59,26 @@ def main():
         losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
         torch.cuda.synchronize()
         dump(out, m, {'losses': losses})
+    elif mode == 'rccl1_split':
+        # the default form of a multi-rank GPU run: ONE message after backward, outside the graphs (fwd+bwd graph | exchange | Adamax graph)
+        os.environ['LVAE_FORCE_DIST'] = '1'
+        rank, world, _ = ldist.init_from_env('nccl')
+        m, opt = build(0)
+        arena = m.pack()
+        ldist.broadcast_flat(arena.params)
+        ar = ldist.GradAllReduce(arena.grads, segments=arena.segments)
+        assert ar.comm is not None, ar.comm_error
+        assert ar.mode == 'split' and not ar.overlap and len(ar.buckets) == 1
+        step = TrainStep(m, opt, use_graph=True, allreduce=ar)
+        losses = [float(step(x.cuda())['loss']) for x in batches(steps, 1)]
+        torch.cuda.synchronize()
+        assert step.graph_a is not None and step.graph_b is not None and 'split' in step.exchange_description()
+        dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'launched': ar.launched})
+        ar.close()
+        torch.distributed.destroy_process_group()
     elif mode == 'rccl1':
         os.environ['LVAE_FORCE_DIST'] = '1'
+        os.environ['LVAE_DDP_MODE'] = 'overlap'
         rank, world, _ = ldist.init_from_env('nccl')
         m, opt = build(0)
         arena = m.pack()
@@ -80,6 +100,7 @@ def main():
         # a collective that refuses to be captured: TrainStep's capture probe finds out before the step is captured and the same process
         # continues with the exchange outside the step graph (fwd+bwd graph | eager all-reduce | Adamax graph)
         os.environ['LVAE_FORCE_DIST'] = '1'
+        os.environ['LVAE_DDP_MODE'] = 'overlap'
         rank, world, _ = ldist.init_from_env('nccl')
         m, opt = build(0)
         arena = m.pack()

@@ -123,6 +123,19 @@ def test_forced_rccl_rank_overlapped_graph_step_matches_single_rank(tmp_path):
     assert nb >= 3 and rb['extra']['launched'] == list(range(nb))     # every bucket exchanged once, in completion order
 
 
+def test_forced_rccl_rank_default_split_exchange_matches_single_rank(tmp_path):
+    """The default exchange of a multi-rank GPU run (one message after backward, between the two graphs) on one forced rank: parameters,
+    BatchNorm statistics and losses of 5 steps equal the plain single-rank run."""
+    a, b = str(tmp_path / 'single.pt'), str(tmp_path / 'split.pt')
+    _run('single', a, 5)
+    _run('rccl1_split', b, 5)
+    ra, rb = torch.load(a), torch.load(b)
+    la, lb = ra['extra']['losses'], rb['extra']['losses']
+    assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 1e-6, (la, lb)
+    assert _max_rel(rb['sd'], ra['sd']) < 1e-6
+    assert rb['extra']['launched'] == [0]
+
+
 def test_capture_refusing_collective_falls_back_to_split_in_process(tmp_path):
     """if the gradient exchange cannot be captured (GradAllReduce.capture_probe meets a refusal), the SAME process
     continues with the exchange outside the step graph; parameters, BatchNorm statistics (incl. num_batches_tracked) and losses equal
