@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int rr = r + u * G;
-          const size_t o = ((size_t)(rr < rows ? rr : g) * 2) * C + c;
+          const size_t o = ((size_t)(rr < rows ? rr : 0) * 2) * C + c;
           pa[u] = f.parts[o];
           pb[u] = f.parts[o + C];
         }

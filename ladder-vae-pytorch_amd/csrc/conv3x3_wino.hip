@@ -183,7 +183,7 @@ __device__ __forceinline__ void wino_fold_bn(const lvae_bn_fold& f, int C, float
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int rr = r + u * G;
-        p[u] = *reinterpret_cast<const f32x4*>(f.parts + ((size_t)(rr < rows ? rr : g) * 2) * C + 4 * q);
+        p[u] = *reinterpret_cast<const f32x4*>(f.parts + ((size_t)(rr < rows ? rr : 0) * 2) * C + 4 * q);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)

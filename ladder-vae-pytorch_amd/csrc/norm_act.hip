@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_parts_kernel(const float
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int rr = r + u * nsl;
-          const size_t o = (size_t)(rr < rows ? rr : rg) * 2 * C + c;
+          const size_t o = (size_t)(rr < rows ? rr : 0) * 2 * C + c;
           pa[u] = *reinterpret_cast<const f32x4*>(parts + o);
           pb[u] = *reinterpret_cast<const f32x4*>(parts + o + C);
         }

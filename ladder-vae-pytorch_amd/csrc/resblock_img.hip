@@ -133,19 +133,38 @@ __device__ __forceinline__ f32x4 rb_act_grad4(f32x4 u, int act) {
   return r;
 }
 
-// Sum of the partial rows [rows][2][64] a producer's statistics epilogue left, by all 256 threads with 16-byte loads, up to 16 in
-// flight per thread (a 256-workgroup producer leaves 128 KB: two round trips instead of one per row), in a fixed order; the 8 row
-// groups are combined in double by threads 0..63, which hand (channel, sum 1, sum 2) to `finish` between the two barriers.
-template <typename F>
-__device__ __forceinline__ void rb_reduce_parts(const float* __restrict__ parts, int rows, float* scr, F&& finish) {
+// Sum of the partial rows [rows][2][64] a producer's statistics epilogue left, by all 256 threads with 16-byte loads, in a fixed order;
+// the 8 row groups are combined in double by threads 0..63, which hand (channel, sum 1, sum 2) to `finish` between the two barriers.
+// Two calls: rb_parts_issue requests the first 256 rows (32 loads per thread in flight) and must come BEFORE the kernel requests its big
+// operand rows: the memory counter of a wave retires in order, so small L2-resident loads issued behind cold HBM loads can only be waited
+// for together with them (in the step the sums used to arrive ~3 us late for exactly that reason: phase 0-1 of tools/rb_stamps_instep.py);
+// rb_parts_finish consumes them (and loops over rows beyond 256, for producers with more workgroups).
+constexpr int RB_PF = 32;
+__device__ __forceinline__ void rb_parts_issue(const float* __restrict__ parts, int rows, f32x4 (&v)[RB_PF]) {
   const int t = threadIdx.x, q = t & 31, rg = t >> 5;   // q: 16-byte piece of a 128-float row; rg: row group (rows rg, rg + 8, ...)
+#pragma unroll
+  for (int u = 0; u < RB_PF; ++u) {
+    const int rr = rg + 8 * u;
+    v[u] = *reinterpret_cast<const f32x4*>(parts + (size_t)(rr < rows ? rr : 0) * 128 + q * 4);
+  }
+}
+template <typename F>
+__device__ __forceinline__ void rb_parts_finish(const float* __restrict__ parts, int rows, const f32x4 (&v0)[RB_PF], float* scr, F&& finish,
+                                                unsigned long long* ts = nullptr) {
+  const int t = threadIdx.x, q = t & 31, rg = t >> 5;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int r = rg; r < rows; r += 8 * 16) {
+#pragma unroll
+  for (int u = 0; u < RB_PF; ++u)
+    if (rg + 8 * u < rows) acc += v0[u];
+#ifdef LVAE_RB_DBG
+  if (ts) { asm volatile("" :: "v"(acc[0])); ts[8] = __builtin_amdgcn_s_memtime(); }
+#endif
+  for (int r = rg + 8 * RB_PF; r < rows; r += 8 * 16) {
     f32x4 v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int rr = r + 8 * u;
-      v[u] = *reinterpret_cast<const f32x4*>(parts + (size_t)(rr < rows ? rr : rg) * 128 + q * 4);
+      v[u] = *reinterpret_cast<const f32x4*>(parts + (size_t)(rr < rows ? rr : 0) * 128 + q * 4);
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u)
@@ -153,6 +172,9 @@ __device__ __forceinline__ void rb_reduce_parts(const float* __restrict__ parts,
   }
   *reinterpret_cast<f32x4*>(scr + rg * 128 + q * 4) = acc;   // [8][128]
   rb_bar();
+#ifdef LVAE_RB_DBG
+  if (ts) ts[9] = __builtin_amdgcn_s_memtime();
+#endif
   if (t < 64) {
     double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -181,6 +203,19 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   constexpr int BM = 64, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
   constexpr int OS_BYTES = BM * LDO * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // The argument block is ~600 bytes = ten cache lines, private to this launch (cold), and hipcc reads it piecemeal where a field is
+  // first used: up to nine dependent s_load -> s_waitcnt pairs spread over the prologue, each a possible miss to memory. One scalar load
+  // per line up front turns them into one round trip (the results are never used).
+  {
+    const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned ka[(sizeof(RbArgs) + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(RbArgs) + 63) / 64); ++i)
+      asm volatile("s_load_dword %0, %1, %2" : "=s"(ka[i]) : "s"(kp), "n"(i * 64) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(RbArgs) + 63) / 64); ++i) asm volatile("" ::"s"(ka[i]));
+  }
   float* scr = reinterpret_cast<float*>(smem_raw);
   unsigned char* mainr = smem_raw + RB_SCR_BYTES;
   // the patch sits behind the dy2 staging tile when the prologue produces it through one (PRO_GATE_BWD)
@@ -222,28 +257,25 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   rb_bar();
 #endif
   RB_STAMP(0);
-  // ---- L2 warm-up. Every convolution of a step has weights of its own, so the 221 KB this workgroup streams are cold in its XCD's L2
-  // when the kernel starts (in-step the launches measured ~4 us longer than back to back on one layer): each wave touches one word of
-  // every 128-byte line of its own slice now (7 loads per lane, in flight during the whole prologue), and the workgroups of an XCD
-  // (round-robin placement: speed only) share the ranges the NEXT launch will stream. The sums are consumed where they are ready anyway.
-  float pf_sum = 0.f;
-  {
-    const float* own = reinterpret_cast<const float*>(a.Wp + (size_t)wave * SPLIT * 1024);   // [tap][4 k blocks][SPLIT][1024] bf16
+  // ---- L2 warm-up for the NEXT launch. Every convolution of a step has weights of its own, so the 221 KB a workgroup streams are cold in
+  // its XCD's L2 when its kernel starts (in-step the launches measured ~4 us longer than back to back on one layer): the workgroups of an
+  // XCD (round-robin placement: speed only) touch one word of every 128-byte line of the ranges the next launch will stream. The touches
+  // are inline-asm loads into registers that nothing reads: written as C++ loads whose values are summed, hipcc waited for each of them
+  // in turn (an s_waitcnt per touch, i.e. a full HBM round trip each, at the very start of the kernel: 6.8 us of phase 0-8 in
+  // tools/rb_stamps_instep.py). The compiler does not count these loads in its s_waitcnt arithmetic; the counter retires in order, so its
+  // waits can only become stricter, never too weak. The destination registers stay reserved until the drain at the end of the kernel.
+  constexpr int PFN = 6;   // touches per lane and range: 6 x 256 lanes x 128 B = 192 KB of a range per workgroup at most
+  unsigned pf_dump[2][PFN];
 #pragma unroll
-    for (int i = 0; i < (9 * SPLIT * 16 + 63) / 64; ++i) {
-      const int line = i * 64 + lane;   // 16 lines of 128 bytes per (tap, plane)
-      const int tap = line / (SPLIT * 16), r = line - tap * (SPLIT * 16);
-      if (line < 9 * SPLIT * 16) pf_sum += own[((size_t)tap * 4 * SPLIT * 1024 + (size_t)r * 64) / 2];
-    }
+  for (int k = 0; k < 2; ++k) {
+    const int per_xcd = (a.nwg + 7) >> 3, part = bid >> 3;
+    const int lines = e.pf_ptr[k] != nullptr ? (int)((e.pf_bytes[k] + 127) >> 7) : 0, per = (lines + per_xcd - 1) / per_xcd;
+    const int lo = part * per, hi = min(lo + per, lines);
+    const char* base = static_cast<const char*>(e.pf_ptr[k]) + (size_t)(lo + t) * 128;   // ranges are far below 2 GB: 32-bit line arithmetic
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (e.pf_ptr[k] != nullptr) {
-        const int per_xcd = (a.nwg + 7) >> 3, part = bid >> 3;
-        const int64_t lines = (e.pf_bytes[k] + 127) >> 7, per = (lines + per_xcd - 1) / per_xcd;
-        const int64_t lo = (int64_t)part * per, hi = lo + per < lines ? lo + per : lines;
-        const float* base = static_cast<const float*>(e.pf_ptr[k]);
-        for (int64_t l = lo + t; l < hi; l += 256) pf_sum += base[l * 32];
-      }
+    for (int i = 0; i < PFN; ++i) {
+      pf_dump[k][i] = 0;
+      if (lo + t + 256 * i < hi) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dump[k][i]) : "v"(base + i * 256 * 128) : "memory");
     }
   }
 
@@ -288,20 +320,22 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     // ---- BatchNorm coefficients of the input: given, or finalized here from the producer's partial sums (conv3x3_pos.hip's fold)
     const lvae_bn_fold& f = a.f;
     const bool has_tf = f.parts != nullptr || d.in_scale != nullptr;
-    // raw loads of the interior first (the finalize's partial rows overlap them)
+    // the producer's partial rows (small, L2-resident) are requested FIRST, the raw rows of the interior (cold, from HBM) behind them: the
+    // finalize then runs while the interior is still in flight
+    f32x4 pv[RB_PF];
+    if (f.parts != nullptr) rb_parts_issue(f.parts, f.rows, pv);
+    const bool lead = t < 64 && f.parts != nullptr;
+    const float pivot = lead ? f.parts[((size_t)f.rows * 2) * 64 + t] : 0.f;  // the producer's pivot, stored behind its partial rows
+    const float gam = lead && f.gamma ? f.gamma[t] : 1.f, bet = lead && f.beta ? f.beta[t] : 0.f;
+    const bool upd = lead && bid == 0 && f.running_mean != nullptr;
+    const float rm0 = upd ? f.running_mean[t] : 0.f, rv0 = upd ? f.running_var[t] : 0.f;
     f32x4 xv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) xv[q] = *reinterpret_cast<const f32x4*>(d.x + grow[q] * 64 + c4);
     zero_ring();   // while the loads are in flight (the patch region is free from the start in this prologue)
     f32x4 sc = one4, sh = zero4;
     if (f.parts != nullptr) {
-      // everything thread c needs after the reduction is requested beside the partial rows, not behind the barrier
-      const bool lead = t < 64;
-      const float pivot = lead ? f.parts[((size_t)f.rows * 2) * 64 + t] : 0.f;  // the producer's pivot, stored behind its partial rows
-      const float gam = lead && f.gamma ? f.gamma[t] : 1.f, bet = lead && f.beta ? f.beta[t] : 0.f;
-      const bool upd = lead && bid == 0 && f.running_mean != nullptr;
-      const float rm0 = upd ? f.running_mean[t] : 0.f, rv0 = upd ? f.running_var[t] : 0.f;
-      rb_reduce_parts(f.parts, f.rows, scr, [&](int c, double sa, double sb) {
+      rb_parts_finish(f.parts, f.rows, pv, scr, [&](int c, double sa, double sb) {
         const double M = (double)f.M, inv_m = 1.0 / M, dm = sa * inv_m;
         double m2 = sb - sa * dm;
         if (m2 < 0.0) m2 = 0.0;
@@ -345,6 +379,13 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     // ---- BatchNorm backward of the block's second (or first) BatchNorm on the way in: d.x = dh (gradient w.r.t. act(BN(x))),
     // e.bwd_x = x; the reduction over the batch was done by the producer's epilogue (partial rows), finalized here by every
     // workgroup in the same order (bitwise identical coefficients); workgroup 0 accumulates dgamma / dbeta
+    // small L2-resident things first (partial rows, coefficients, accumulators), the cold operand rows behind them (in-order memory counter)
+    f32x4 pv[RB_PF];
+    rb_parts_issue(e.bwd_parts, e.bwd_rows, pv);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(e.bwd_coef + c4), sh = *reinterpret_cast<const f32x4*>(e.bwd_coef + 64 + c4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(e.bwd_coef + 128 + c4), rs = *reinterpret_cast<const f32x4*>(e.bwd_coef + 192 + c4);
+    const bool acc_here = bid == 0 && t < 64;
+    const float db0 = acc_here && e.dbeta ? e.dbeta[t] : 0.f, dg0 = acc_here && e.dgamma ? e.dgamma[t] : 0.f;
     f32x4 gv[NQ], xv[NQ], dm[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -353,18 +394,18 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       dm[q] = e.pro_drop ? *reinterpret_cast<const f32x4*>(e.pro_drop + (size_t)img_n[q] * 64 + c4) : one4;
     }
     zero_ring();   // while the loads are in flight
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(e.bwd_coef + c4), sh = *reinterpret_cast<const f32x4*>(e.bwd_coef + 64 + c4);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(e.bwd_coef + 128 + c4), rs = *reinterpret_cast<const f32x4*>(e.bwd_coef + 192 + c4);
-    const bool acc_here = bid == 0 && t < 64;
-    const float db0 = acc_here && e.dbeta ? e.dbeta[t] : 0.f, dg0 = acc_here && e.dgamma ? e.dgamma[t] : 0.f;
-    rb_reduce_parts(e.bwd_parts, e.bwd_rows, scr, [&](int c, double sa, double sb) {
+    rb_parts_finish(e.bwd_parts, e.bwd_rows, pv, scr, [&](int c, double sa, double sb) {
       scr[1024 + c] = (float)(sa / (double)e.bwd_M);
       scr[1024 + 64 + c] = (float)(sb / (double)e.bwd_M);
       if (bid == 0) {
         if (e.dbeta) e.dbeta[c] = db0 + (float)sa;
         if (e.dgamma) e.dgamma[c] = dg0 + (float)sb;
       }
-    });
+    }
+#ifdef LVAE_RB_DBG
+    , rb_ts
+#endif
+    );
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(scr + 1024 + c4), c2 = *reinterpret_cast<const f32x4*>(scr + 1024 + 64 + c4);
     RB_STAMP(1);
 #pragma unroll
@@ -686,7 +727,12 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       if (bid == 0 && which == 0 && stats_fwd) stats_out[((size_t)a.nwg * 2) * 64 + c] = stats_pivot[c];
     }
   }
-  if (pf_sum == 1.2345678e-30f) scr[2047] = pf_sum;   // keeps the warm-up loads alive (never true for weight bytes read as floats, harmless if it were)
+  // the warm-up touches have long landed; drain the counter before their registers are released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) asm volatile("" ::"v"(pf_dump[k][i]));
   RB_STAMP(7);
 #ifdef LVAE_RB_DBG_REPS
   }

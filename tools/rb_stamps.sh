@@ -10,3 +10,4 @@ OBJS=$(ls *.o | grep -v resblock_img.o | tr '\n' ' ')
 /opt/rocm/bin/hipcc $FLAGS -DLVAE_RB_DBG $RB_EXTRA -c resblock_img.hip -o rb_dbg.o && /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o $DBG/lib_rb.so $OBJS rb_dbg.o
 cd $GRAFT_REPO_ROOT
 for H in ${HS:-8 4 2}; do python tools/rb_stamps.py $H $DBG/lib_rb.so 2>&1 | grep -v Warning; done
+if [ -n "$INSTEP" ]; then python tools/rb_stamps_instep.py $DBG/lib_rb.so 2>&1 | grep -v "Warning\|amdgpu"; fi
