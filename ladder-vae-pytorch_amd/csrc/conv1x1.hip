@@ -31,6 +31,7 @@ struct PwArgs {
 
 template <int BM, int KT, int NT, bool B_KCONTIG>
 __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
+  kernarg_warmup<(sizeof(PwArgs) < 1024 ? sizeof(PwArgs) : 1024)>();
   constexpr int LDA = KT + 4;
   constexpr int K4 = KT / 4;
   constexpr int WMT = BM / 2, MI = WMT / 32, NI = NT / 64;

@@ -49,6 +49,7 @@ constexpr int GB_LDA = 132;  // dab / weight row pitch (floats): conflict-free d
 constexpr int GB_LDY = 68;   // y / dx staging row pitch
 
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) {
+  kernarg_warmup<(sizeof(GbfArgs) < 1024 ? sizeof(GbfArgs) : 1024)>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                       // [64 ci][132]: W[co][ci] as B[k = co][n = ci], k-contiguous
   float* As = Bs + 64 * GB_LDA;           // [64 px][132]: dab tile (A of the dgrad, B of the weight gradient); later dx staging
@@ -201,6 +202,7 @@ constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 
 // takes 8 channels of ONE pixel row per tile (5 loads of 16 bytes instead of 8, one 16-byte store instead of two of 8).
 template <int SPLIT, bool S16 = false>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
+  kernarg_warmup<sizeof(GbfArgs)>();
   static_assert(SPLIT == 1 || !S16, "bf16 storage exists for the bf16-operand form only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int A_PLANE = 64 * GBB_LDA, Y_PLANE = 64 * GBB_LDY;

@@ -57,6 +57,7 @@ constexpr int GF_PLANE = GF_BM * GF_LDB;  // bf16 elements per piece
 // tile is two 16-byte loads per thread copied straight into the bf16 LDS image, and ab leaves as 8 channels per lane.
 template <bool WT, int SPLIT, bool S16 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a) {
+  kernarg_warmup<(sizeof(GateFwdArgs) < 1024 ? sizeof(GateFwdArgs) : 1024)>();
   static_assert(!S16 || (WT && SPLIT == 1), "bf16 storage: write-through form, bf16 operands");
   constexpr bool BF16 = SPLIT > 0;
   constexpr int NPIECE = SPLIT > 0 ? SPLIT : 1;

@@ -23,6 +23,7 @@ struct W1x1Args {
 
 template <int NB>  // 32-wide output-channel blocks: Cout = 32 * NB
 __global__ __launch_bounds__(256, 1) void conv1x1_wgrad_kernel(W1x1Args a) {
+  kernarg_warmup<(sizeof(W1x1Args) < 1024 ? sizeof(W1x1Args) : 1024)>();
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [4 waves][2][NB][16][64] + [4][NB][32]
   constexpr int PER_WAVE = 2 * NB * 16 * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;

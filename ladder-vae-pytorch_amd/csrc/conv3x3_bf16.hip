@@ -49,6 +49,7 @@ constexpr int BF_LDK = 72;   // bf16 elements per LDS row (64 channels + 8 pad =
 // (bf16 in / fp32 out) take the generic path with the descriptor's run-time dtype flags.
 template <int SPLIT, int MI, bool PRE = false, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
+  kernarg_warmup<(sizeof(BfArgs) < 1024 ? sizeof(BfArgs) : 1024)>();
   static_assert(SPLIT == 1 || (!XB && !YB), "bf16 storage exists for the bf16-operand form only");
   constexpr int BM = 64 * MI, LDK = BF_LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -441,6 +442,7 @@ struct BfWgArgs {
 // dtype flags are honoured with 4-channel accesses.
 template <int MI, int SPLIT, bool XB = false, bool DB = false>  // tile = 64 * MI pixels
 __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
+  kernarg_warmup<(sizeof(BfWgArgs) < 1024 ? sizeof(BfWgArgs) : 1024)>();
   static_assert(SPLIT == 1 || (!XB && !DB), "bf16 storage exists for the bf16-operand form only");
   constexpr int BM = 64 * MI, LDK = BF_LDK, KS = BM / 16;   // k-steps of 16 pixels per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -24,6 +24,7 @@ struct HaloArgs {
 
 template <int BM, int CIN_T, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
+  kernarg_warmup<(sizeof(HaloArgs) < 1024 ? sizeof(HaloArgs) : 1024)>();
   constexpr int LDA = CIN_T + 4;   // A / k-contiguous B row stride (floats)
   constexpr int LDN = 64;          // n-contiguous B row stride
   // BM = 32 (low-resolution layers): the 4 waves are 2 (co halves) x 2 (K groups); both K groups work on every stage

@@ -31,6 +31,7 @@ constexpr int kPosNotEligible = -1000;
 
 template <int CIN_T, bool B_KCONTIG>
 __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
+  kernarg_warmup<(sizeof(PosArgs) < 1024 ? sizeof(PosArgs) : 1024)>();
   constexpr int LDA = CIN_T + 4;             // A row pitch (floats): conflict-free ds_read_b128 (as conv3x3_halo.hip)
   constexpr int CIN4 = CIN_T / 4;            // float4 per A row
   constexpr int RPP = 256 / CIN4;            // A rows per pass of the 256 threads (16 at 64 channels, 32 at 32)

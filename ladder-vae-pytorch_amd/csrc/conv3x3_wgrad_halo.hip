@@ -37,6 +37,7 @@ struct WTileArgs {
 
 template <int CIN_T, int NKW>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WTileArgs a) {
+  kernarg_warmup<(sizeof(WTileArgs) < 1024 ? sizeof(WTileArgs) : 1024)>();
   const int grp = blockIdx.x;
 #include "conv3x3_wgrad_halo_body.inc"
 }
@@ -51,6 +52,7 @@ static_assert(sizeof(WTileGroup) <= 4096, "kernel argument block");
 
 template <int CIN_T, int NKW>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_grouped_kernel(WTileGroup g) {
+  kernarg_warmup<(sizeof(WTileGroup) < 1024 ? sizeof(WTileGroup) : 1024)>();
   const WTileArgs& a = g.p[blockIdx.y];
   if ((int)blockIdx.x >= a.ncot * a.ksplit) return;  // uniform per workgroup, before any barrier
   const int grp = blockIdx.x;

@@ -36,6 +36,7 @@ constexpr int WG_DS = 80;  // dy pixel stride (floats, 64 channels + pad): 2 pix
 
 template <int TPR>  // Winograd tiles per image row (W / 2): 4, 8 or 16; a chunk is 16 tiles = 16 / TPR tile rows
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(WgWinoArgs a) {
+  kernarg_warmup<sizeof(WgWinoArgs)>();
   const int nwg_ = gridDim.x;
 #include "conv3x3_wgrad_wino_body.inc"
 }
@@ -49,6 +50,7 @@ static_assert(sizeof(WgWinoGroup) <= 4096, "kernel argument block");
 // several independent problems in one launch (blockIdx.y = problem): the 8x8 level fills half the CUs per problem
 template <int TPR>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_grouped_kernel(WgWinoGroup g) {
+  kernarg_warmup<(sizeof(WgWinoGroup) < 1024 ? sizeof(WgWinoGroup) : 1024)>();
   const WgWinoArgs& a = g.p[blockIdx.y];
   const int nwg_ = a.nranges * a.ncog * 2;
   if ((int)blockIdx.x >= nwg_) return;  // uniform per workgroup, before any barrier
@@ -139,12 +141,14 @@ __device__ __forceinline__ void wino_reduce_body(const WinoReduceArgs& a, int bx
 }
 
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_kernel(WinoReduceArgs a) {
+  kernarg_warmup<sizeof(WinoReduceArgs)>();
   __shared__ __attribute__((aligned(16))) float red[8 * 16 * 32];
   __shared__ float red_b[16][64];
   wino_reduce_body<true>(a, blockIdx.x, red, red_b);
 }
 
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_reduce_grouped_kernel(WinoReduceGroup g) {
+  kernarg_warmup<(sizeof(WinoReduceGroup) < 1024 ? sizeof(WinoReduceGroup) : 1024)>();
   const WinoReduceArgs& a = g.p[blockIdx.y];
   if ((int)blockIdx.x >= 64 * a.ncog) return;   // uniform per workgroup, before any barrier
   __shared__ __attribute__((aligned(16))) float red[8 * 16 * 64];

@@ -260,6 +260,7 @@ __device__ unsigned long long g_wino_stamps[8192 * 8];
 // v_mfma_f32_32x32x16_bf16 has its own unit, costs 6/16 per fp32-equivalent product and runs beside the vector work.
 template <int CIN, int NH, int MT, bool SPL>
 __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
+  kernarg_warmup<(sizeof(WinoArgs) < 1024 ? sizeof(WinoArgs) : 1024)>();
   static_assert(!SPL || (CIN == 64 && MT == 1 && NH == 2), "six-product form: 64 reduction channels, 128-pixel workgroups");
   constexpr int WLDA = CIN + 4;     // halo pixel stride (floats)
   constexpr int KSTEPS = CIN / 8, NSLICE = CIN / 16;
@@ -647,6 +648,7 @@ constexpr int W2_LDS_R = 8 * 2 * 32 * WLDO * 4;  // bytes of the partial-sum exc
 // becomes ~50 MB of stores and one residual read inside a launch that is already there.
 template <bool GATE>
 __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
+  kernarg_warmup<sizeof(WinoArgs)>();
   constexpr int CIN = 64, WLDA = CIN + 4, NSLICE = CIN / 16, CW = 64, C4N = CW / 4, PG = 512 / C4N, NH = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;  // [halo_px][WLDA]; reused as the partial sums [wave 8][b 2][32 tiles][WLDO] by the epilogue

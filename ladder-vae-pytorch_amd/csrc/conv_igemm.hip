@@ -48,6 +48,7 @@ __device__ __forceinline__ bool tap_coord(int o, int k, int stride, int pad, int
 
 template <int BM, int BN, bool A_VEC, int B_MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  kernarg_warmup<(sizeof(ConvArgs) < 1024 ? sizeof(ConvArgs) : 1024)>();
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int AP = BM / 32;          // float4 A loads per thread per stage (vector path)
   constexpr int BP = BN / 32;          // float4 B loads per thread per stage (vector paths)

@@ -41,6 +41,7 @@ __device__ __forceinline__ bool tap_coord_w(int o, int k, int stride, int pad, i
 
 template <bool X_VEC, bool Y_VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  kernarg_warmup<(sizeof(WgradArgs) < 1024 ? sizeof(WgradArgs) : 1024)>();
   __shared__ __attribute__((aligned(16))) float Xs[2][KP][CT];
   __shared__ __attribute__((aligned(16))) float Ys[2][KP][CT];
   const lvae_conv_desc& d = a.d;
@@ -323,6 +324,7 @@ struct ReduceGroup {
 
 // blockIdx.y = problem; same element mapping as wgrad_reduce_kernel<4> (all grouped problems are float4-aligned)
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(ReduceGroup g) {
+  kernarg_warmup<(sizeof(ReduceGroup) < 1024 ? sizeof(ReduceGroup) : 1024)>();
   __shared__ float red[16][16 * 4];
   const ReduceArgs& a = g.p[blockIdx.y];
   const int per = a.ntaps * a.Cin * a.Cout;
@@ -407,6 +409,7 @@ struct ThinWgradArgs {
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinWgradArgs a) {
+  kernarg_warmup<(sizeof(ThinWgradArgs) < 1024 ? sizeof(ThinWgradArgs) : 1024)>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const lvae_conv_desc& d = a.d;
   const int t = threadIdx.x, n = blockIdx.x;

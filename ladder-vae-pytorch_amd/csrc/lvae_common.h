@@ -85,6 +85,27 @@ __device__ __forceinline__ void store_wt4(float* p, f32x4 v) {
 // goes through LDS, only the LDS counter has to drain.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Kernel-argument warm-up. A launch's argument block is private to it (cold in the scalar cache and in L2), and hipcc reads a large block
+// piecemeal, where a field is first used: several dependent s_load -> s_waitcnt pairs spread over the prologue, each a possible miss to
+// memory. One scalar load per 64-byte line up front turns them into ONE round trip; the results are never used. -DLVAE_KERNARG_WARM=0
+// compiles it out (A/B builds, tools/kernarg_ab.sh).
+#ifndef LVAE_KERNARG_WARM
+#define LVAE_KERNARG_WARM 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warmup() {
+#if LVAE_KERNARG_WARM
+  const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int NL = (BYTES + 63) / 64;
+  unsigned ka[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("s_load_dword %0, %1, %2" : "=s"(ka[i]) : "s"(kp), "n"(i * 64) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("" ::"s"(ka[i]));
+#endif
+}
+
 constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
 constexpr float kSeluScale = 1.0507009873554804934193349852946f;
 

@@ -203,19 +203,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   constexpr int BM = 64, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
   constexpr int OS_BYTES = BM * LDO * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // The argument block is ~600 bytes = ten cache lines, private to this launch (cold), and hipcc reads it piecemeal where a field is
-  // first used: up to nine dependent s_load -> s_waitcnt pairs spread over the prologue, each a possible miss to memory. One scalar load
-  // per line up front turns them into one round trip (the results are never used).
-  {
-    const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned ka[(sizeof(RbArgs) + 63) / 64];
-#pragma unroll
-    for (int i = 0; i < (int)((sizeof(RbArgs) + 63) / 64); ++i)
-      asm volatile("s_load_dword %0, %1, %2" : "=s"(ka[i]) : "s"(kp), "n"(i * 64) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < (int)((sizeof(RbArgs) + 63) / 64); ++i) asm volatile("" ::"s"(ka[i]));
-  }
+  kernarg_warmup<sizeof(RbArgs)>();   // ~600 bytes = ten cache lines, read piecemeal by up to nine dependent s_load batches otherwise
   float* scr = reinterpret_cast<float*>(smem_raw);
   unsigned char* mainr = smem_raw + RB_SCR_BYTES;
   // the patch sits behind the dy2 staging tile when the prologue produces it through one (PRO_GATE_BWD)
