@@ -281,6 +281,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
       const size_t ybase = ((size_t)(n0 * d.H + oh0) * d.W) * d.Cout + col;
       const bool sxbf = d.stats_x_dtype == LVAE_DT_BF16;
       const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
+      // the BatchNorm input rows of the backward sums are requested BEFORE the first store of this pass: a wave's memory counter retires in
+      // order, so a load issued behind a write-through store waits for that store's trip to memory (conv3x3_wino.hip, round 4)
+      f32x4 sx0[BM / 32], sx1[BM / 32];
+      if (bwd && d.stats_out) {
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) {
+          const int p = p0 + 32 * q, pc = p < nvalid ? p : 0;
+          const size_t xo = (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col;
+          if (sxbf) {
+            const bf16x8 xq = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.stats_x) + xo);
+            sx0[q] = f32x4{(float)xq[0], (float)xq[1], (float)xq[2], (float)xq[3]};
+            sx1[q] = f32x4{(float)xq[4], (float)xq[5], (float)xq[6], (float)xq[7]};
+          } else {
+            sx0[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo);
+            sx1[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo + 4);
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < BM / 32; ++q) {
         const int p = p0 + 32 * q;
@@ -299,16 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
           asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(yb16 + ybase + (size_t)p * d.Cout), "v"(o) : "memory");
           if (bwd) {
             if (d.stats_out) {
-              const size_t xo = (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col;
-              f32x4 xv[2];
-              if (sxbf) {
-                const bf16x8 xq = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.stats_x) + xo);
-                xv[0] = f32x4{(float)xq[0], (float)xq[1], (float)xq[2], (float)xq[3]};
-                xv[1] = f32x4{(float)xq[4], (float)xq[5], (float)xq[6], (float)xq[7]};
-              } else {
-                xv[0] = *reinterpret_cast<const f32x4*>(d.stats_x + xo);
-                xv[1] = *reinterpret_cast<const f32x4*>(d.stats_x + xo + 4);
-              }
+              const f32x4 xv[2] = {sx0[q], sx1[q]};
 #pragma unroll
               for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -365,6 +374,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
     const bool ybf = d.y_dtype == LVAE_DT_BF16, sxbf = d.stats_x_dtype == LVAE_DT_BF16;
     const float* op = Os + p0 * LDO + c4;
     const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
+    f32x4 sxr[BM / 16];   // BatchNorm input rows of the backward sums, requested before the first store of the pass (see above)
+    if (d.stats_mode == LVAE_STATS_BN_BWD && d.stats_out) {
+#pragma unroll
+      for (int q = 0; q < BM / 16; ++q) {
+        const int p = p0 + 16 * q, pc = p < nvalid ? p : 0;
+        sxr[q] = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col, sxbf);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < BM / 16; ++q) {
       const int p = p0 + 16 * q;
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
         store4_dt(d.y, ybase + (size_t)q * 16 * d.Cout, v, ybf);
         if (d.stats_mode == LVAE_STATS_BN_BWD) {
           if (d.stats_out) {
-            const f32x4 xv = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col, sxbf);
+            const f32x4 xv = sxr[q];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
