@@ -695,6 +695,286 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_bf16_kernel(BfWgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Half-slab form of the bf16 weight gradient (round 4; 64 -> 64 channels, 128-pixel tiles, >= 512 tiles). The form above gives every
+// workgroup the whole [9][64][64] gradient, so its 256 workgroups write 256 x 147 KB = 37.7 MB of partial slabs per launch and the reduce
+// reads them back: ~19 of the 34 us a 256x16x16 gradient costs in the step, for 2 us of MFMAs; and a tile costs it ~5 us (operands fetched
+// one tile ahead, two barriers, 4-5 taps per wave), so fewer workgroups with more tiles each lost (2 tiles per workgroup 33.3 ms / step,
+// 4: 33.7, 8: 36.1). Here a workgroup owns the 32 INPUT channels `cih` of the gradient over twice the pixels: 128 pixel ranges x 2 halves
+// = 256 workgroups, 128 slabs, 18.8 MB written and re-read. It stages only its half of the x patch - the BatchNorm + ELU of the staging is
+// vector-ALU work that must not be replicated: a first build with (ci half, co half) quadrants and four waves spent 13 of its 39 us there -
+// and the whole dy tile; waves = co half x tap group {0,1,2} {3,4} {5,6} {7,8} (<= 3 accumulator tiles), the LDS images are double-buffered
+// (one barrier per tile) and the raw operands are fetched TWO tiles ahead in two register sets.
+// The two halves of a pixel range read the same dy lines: same XCD, consecutive dispatch slots. Slab layout and the fixed-order reduce are
+// the ones of the form above (the two halves of a range fill one slab): deterministic.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef LVAE_BFH_LDK
+#define LVAE_BFH_LDK 72
+#endif
+constexpr int BFH_LDK = LVAE_BFH_LDK;   // bf16 elements per LDS row of this kernel's images
+
+template <bool XB, bool DB>
+struct BfHRegs {
+  bf16x8 x8[XB ? 2 : 1];
+  f32x4 x4[XB ? 1 : 4];
+  bf16x8 d8[DB ? 2 : 1];
+  f32x4 d4[DB ? 1 : 4];
+  unsigned xok, dok;
+};
+
+template <bool XB, bool DB>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_bf16h_kernel(BfWgArgs a) {
+  kernarg_warmup<(sizeof(BfWgArgs) < 1024 ? sizeof(BfWgArgs) : 1024)>();
+  constexpr int BM = 128, LDK = BFH_LDK, KS = BM / 16;
+#ifdef LVAE_BFH_DBG  // compile-time phase-skip mask of the profiling builds (tools/bfq_phase.sh); never defined in the product
+  constexpr int dbg = LVAE_BFH_DBG;  // 1: no k-steps, 2: no staging, 4: no global loads, 8: no slab stores, 16: no input transform
+#else
+  constexpr int dbg = 0;
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int img_elems = (a.halo_px + BM) * LDK;   // one image: x patch [halo_px][LDK] (32 channels used) then dy tile [BM][LDK]
+  __bf16* const buf0 = reinterpret_cast<__bf16*>(smem_raw);
+  const lvae_conv_desc& d = a.d;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int coh = wave & 1, tg = wave >> 1;
+  const int tap0 = tg == 0 ? 0 : 2 * tg + 1, ntap = tg == 0 ? 3 : 2;
+  const int li = lane & 31, lh = lane >> 5, G = lane >> 4, i16 = lane & 15;
+  // workgroup -> (pixel range, ci half): XCD = range % 8, the two halves of a range are consecutive workgroups of that XCD
+  const int nrange = gridDim.x >> 1;
+  int range, cih;
+  if ((nrange & 7) == 0) {
+    const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3;
+    cih = g & 1;
+    range = (g >> 1) * 8 + xcd;
+  } else {
+    cih = blockIdx.x & 1;
+    range = blockIdx.x >> 1;
+  }
+  const int Cin = a.Cin;   // == 64 == d.Cout (host)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int chx = 16 * (G & 1) + 4 * (i16 & 3);   // channel offset of this lane's 8-byte piece inside the staged x half
+  const int chd = coh * 32 + chx;                  // ... inside a dy row
+  const int drow0 = 8 * (G >> 1) + (i16 >> 2);
+  // element offset (inside an image) of this lane's two transposed reads of k-step s at tap (0, 0): the same for every tile, so the two
+  // magic divisions per read are paid once per kernel (16 registers) instead of once per k-step and tile
+  int xoff[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int p = 16 * s + 8 * (G >> 1) + 4 * rd + (i16 >> 2);
+      const int img = fastdiv(p, a.m_thw), r = p - img * (a.TH * a.TW);
+      const int ty = fastdiv(r, a.m_tw), tx = r - ty * a.TW;
+      xoff[s][rd] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDK + chx;
+    }
+  int tapoff[3];   // wave-uniform
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = tap0 + (j < ntap ? j : 0), kh = tap / 3, kw = tap - kh * 3;
+    tapoff[j] = (kh * a.halo_w + kw) * LDK;
+  }
+
+  // ---- staging maps (512 threads). x half, bf16-stored: (pixel t >> 2 + 128 u, 8 channels), fp32-stored: (pixel t >> 3 + 64 u, 4 channels);
+  // dy, bf16-stored: (pixel t >> 3 + 64 u, 8 channels), fp32-stored: (pixel t >> 4 + 32 u, 4 channels)
+  const int xcl = XB ? (t & 3) * 8 : (t & 7) * 4, xpx = XB ? t >> 2 : t >> 3;
+  const int dcl = DB ? (t & 7) * 8 : (t & 15) * 4, dpx = DB ? t >> 3 : t >> 4;
+  const int xc = cih * 32 + xcl;   // global channel of this thread's x piece
+  f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sh0 = zero4, sc1 = sc0, sh1 = zero4;
+  if (d.in_scale) {
+    sc0 = *reinterpret_cast<const f32x4*>(d.in_scale + xc);
+    sh0 = *reinterpret_cast<const f32x4*>(d.in_shift + xc);
+    if (XB) {
+      sc1 = *reinterpret_cast<const f32x4*>(d.in_scale + xc + 4);
+      sh1 = *reinterpret_cast<const f32x4*>(d.in_shift + xc + 4);
+    }
+  }
+  const int per_img = a.halo_h * a.halo_w;
+  const bool xbf = d.x_dtype == LVAE_DT_BF16, dybf = d.y_dtype == LVAE_DT_BF16;
+  // tile-invariant part of the staging loads: image / row of the slot inside the tile, element offset relative to the tile's (n0, oh0, 0)
+  constexpr int XU = XB ? 2 : 4, DU = DB ? 2 : 4;
+  int ximg[XU], xhy[XU], xrel[XU], dimg[DU], drel[DU];
+  unsigned xcolok = 0;
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int px = xpx + (XB ? 128 : 64) * u;
+    const int img = fastdiv(px, a.m_per_img), r = px - img * per_img;
+    const int hy = fastdiv(r, a.m_halo_w), hx = r - hy * a.halo_w;
+    ximg[u] = img;
+    xhy[u] = hy - 1;
+    xrel[u] = ((img * d.H + hy - 1) * d.W + hx - 1) * Cin + xc;
+    xcolok |= ((px < a.halo_px) & ((unsigned)(hx - 1) < (unsigned)d.W)) ? (1u << u) : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < DU; ++u) {
+    const int p = dpx + (DB ? 64 : 32) * u;
+    dimg[u] = fastdiv(p, a.m_thw);
+    drel[u] = p * d.Cout + dcl;
+  }
+  auto prefetch = [&](int tile, BfHRegs<XB, DB>& R) {
+    const int ig = fastdiv(tile, a.m_tiles_h), th_idx = tile - ig * a.tiles_h;
+    const int n0 = ig * a.NI, oh0 = th_idx * a.TH;
+    const int tbase = (n0 * d.H + oh0) * d.W;   // pixel index of the tile's first output pixel (M * 64 < 2^31: host)
+    R.xok = 0;
+    R.dok = 0;
+    if (dbg & 4) {
+#pragma unroll
+      for (int u = 0; u < (XB ? 2 : 1); ++u) R.x8[u] = zero8;
+#pragma unroll
+      for (int u = 0; u < (XB ? 1 : 4); ++u) R.x4[u] = zero4;
+#pragma unroll
+      for (int u = 0; u < (DB ? 2 : 1); ++u) R.d8[u] = zero8;
+#pragma unroll
+      for (int u = 0; u < (DB ? 1 : 4); ++u) R.d4[u] = zero4;
+      R.xok = R.dok = tile & 1;
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const bool ok = ((xcolok >> u) & 1u) & (n0 + ximg[u] < d.N) & ((unsigned)(oh0 + xhy[u]) < (unsigned)d.H);
+      const unsigned off = ok ? (unsigned)(tbase * Cin + xrel[u]) : 0u;
+      if (XB) R.x8[XB ? u : 0] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.x) + off);
+      else R.x4[XB ? 0 : u] = load4_dt(d.x, off, xbf);
+      R.xok |= ok ? (1u << u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const bool ok = n0 + dimg[u] < d.N;
+      const unsigned off = ok ? (unsigned)(tbase * d.Cout + drel[u]) : 0u;
+      if (DB) R.d8[DB ? u : 0] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.dy) + off);
+      else R.d4[DB ? 0 : u] = load4_dt(a.dy, off, dybf);
+      R.dok |= ok ? (1u << u) : 0u;
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f32x4 bsum = zero4, bsum8 = zero4;   // bias-gradient partials of this thread's dy channels (bsum8: channels + 4 .. + 7 of an 8-channel piece)
+
+  // registers -> LDS image (transform + round to bf16; rows that do not exist are zero)
+  auto stage = [&](BfHRegs<XB, DB>& R, __bf16* Xs) {
+    if (dbg & 2) return;
+    __bf16* Ds = Xs + a.halo_px * LDK;
+#pragma unroll
+    for (int u = 0; u < (XB ? 2 : 4); ++u) {
+      const int px = xpx + (XB ? 128 : 64) * u;
+      if (px < a.halo_px) {
+        if (XB) {
+          bf16x8 w = R.x8[XB ? u : 0];
+          if (d.in_scale && !(dbg & 16)) {
+            f32x4 lo = {(float)w[0], (float)w[1], (float)w[2], (float)w[3]}, hi = {(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+            lo = act_fwd4(lo * sc0 + sh0, d.in_act);
+            hi = act_fwd4(hi * sc1 + sh1, d.in_act);
+            w = to_bf16x8(lo, hi);
+          }
+          if (!((R.xok >> u) & 1u)) w = zero8;
+          *reinterpret_cast<bf16x8*>(Xs + px * LDK + xcl) = w;
+        } else {
+          f32x4 w = zero4;
+          if ((R.xok >> u) & 1u) {
+            w = R.x4[XB ? 0 : u];
+            if (d.in_scale && !(dbg & 16)) w = act_fwd4(w * sc0 + sh0, d.in_act);
+          }
+          *reinterpret_cast<bf16x4*>(Xs + px * LDK + xcl) = to_bf16x4(w);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (DB ? 2 : 4); ++u) {
+      const int p = dpx + (DB ? 64 : 32) * u;
+      if (DB) {
+        const bf16x8 w = ((R.dok >> u) & 1u) ? R.d8[DB ? u : 0] : zero8;
+        bsum += f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+        bsum8 += f32x4{(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+        *reinterpret_cast<bf16x8*>(Ds + p * LDK + dcl) = w;
+      } else {
+        const f32x4 w = ((R.dok >> u) & 1u) ? R.d4[DB ? 0 : u] : zero4;
+        bsum += w;
+        *reinterpret_cast<bf16x4*>(Ds + p * LDK + dcl) = to_bf16x4(w);
+      }
+    }
+  };
+  auto mma_tile = [&](const __bf16* Xs) {
+    if (dbg & 1) return;
+    const __bf16* Ds = Xs + a.halo_px * LDK;
+    const __bf16* Dl = Ds + drow0 * LDK + chd;
+    // the 48 read addresses of a tile are loop-invariant; hoisted out of the tile loop (as hipcc does) they cost 96 registers and spill.
+    // Passing the scalar tap offsets through an empty asm per tile keeps each address one v_add next to its read.
+    int tb[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      tb[j] = tapoff[j];
+      asm volatile("" : "+s"(tb[j]));
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 bfr = tr_frag(Dl + 16 * s * LDK, Dl + (16 * s + 4) * LDK);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (j < ntap) {
+          const bf16x8 afr = tr_frag(Xs + xoff[s][0] + tb[j], Xs + xoff[s][1] + tb[j]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[j], 0, 0, 0);
+        }
+      }
+      if (s & 1) __builtin_amdgcn_sched_barrier(0);   // fragments of two k-steps in flight, not of all eight (registers)
+    }
+  };
+
+  // tiles range, range + nrange, ...: two register sets, two LDS images
+  BfHRegs<XB, DB> R0, R1;
+  const int stride = nrange;
+  int tile = range;
+  if (tile < a.ntiles) prefetch(tile, R0);
+  if (tile + stride < a.ntiles) prefetch(tile + stride, R1);
+  for (; tile < a.ntiles; tile += 2 * stride) {
+    stage(R0, buf0);
+    __syncthreads();   // image 0 is published; every wave has left the k-steps of the tile before last, which read image 0
+    if (tile + 2 * stride < a.ntiles) prefetch(tile + 2 * stride, R0);
+    mma_tile(buf0);
+    if (tile + stride >= a.ntiles) break;
+    stage(R1, buf0 + img_elems);
+    __syncthreads();
+    if (tile + 3 * stride < a.ntiles) prefetch(tile + 3 * stride, R1);
+    mma_tile(buf0 + img_elems);
+  }
+
+  // ---- this half of the range's slab straight from the accumulators (row = ci, 32 consecutive co per lane half)
+  float* sw = a.slab_w + (size_t)range * 9 * Cin * d.Cout;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < ntap) {
+      const int tap = tap0 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = coh * 32 + li;
+        if (!(dbg & 8) || acc[j][r] == 12345.678f) sw[((size_t)tap * Cin + ci) * d.Cout + co] = acc[j][r];
+      }
+    }
+  }
+  if (a.slab_b && cih == 0) {   // uniform per workgroup
+    __syncthreads();            // every wave is done with the images
+    float* red = reinterpret_cast<float*>(smem_raw);   // [pixel groups][64]
+    constexpr int NG = DB ? 64 : 32;
+    if (DB) {
+      *reinterpret_cast<f32x4*>(red + dpx * 64 + dcl) = bsum;
+      *reinterpret_cast<f32x4*>(red + dpx * 64 + dcl + 4) = bsum8;
+    } else {
+      *reinterpret_cast<f32x4*>(red + dpx * 64 + dcl) = bsum;
+    }
+    __syncthreads();
+    if (t < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) v += red[g * 64 + t];
+      a.slab_b[(size_t)range * d.Cout + t] = v;
+    }
+  }
+}
+
 static bool al16b(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- weight pre-split: piece `plane` of w[tap][k][n] (any strides) in MFMA B-fragment order, zero beyond K / N
@@ -994,10 +1274,26 @@ static int bfwg_nwg(const BfWgArgs& a) {
   return n;
 }
 
+// pixel ranges (= slabs) of the half-slab form, 0 when the layer keeps the form above: 64 -> 64 channels, 128-pixel tiles, at least 512 of
+// them (4 per workgroup at 256x16x16, 16 at 256x32x32)
+#ifndef LVAE_BF16_WGRAD_HALF
+#define LVAE_BF16_WGRAD_HALF 1
+#endif
+static int bfwg_half_ranges(const lvae_conv_desc* d, const BfWgArgs& a) {
+  static const bool on = tune("LVAE_BF16_WGRAD_HALF", LVAE_BF16_WGRAD_HALF) != 0;  // A/B switch (tuning builds only)
+  if (!on || a.split != 1 || d->C1 != 64 || d->Cout != 64 || a.bm != 128 || a.ntiles < 512) return 0;
+  if ((size_t)2 * (a.halo_px + 128) * BFH_LDK * 2 > 159 * 1024) return 0;
+  // both operands fp32-stored (the layers outside the bf16-storage blocks): two register sets of 4-channel pieces do not fit beside the
+  // accumulators (20 registers spilled, 30.5 us against 30.1 us for the form above)
+  if (d->x_dtype != LVAE_DT_BF16 && d->y_dtype != LVAE_DT_BF16) return 0;
+  return 128;
+}
+
 size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d) {
   BfWgArgs a;
   if (!bfwg_plan(d, a)) return 0;
-  return (size_t)bfwg_nwg(a) * ((size_t)9 * d->C1 * d->Cout + d->Cout) * sizeof(float);
+  const int q = bfwg_half_ranges(d, a);
+  return (size_t)(q ? q : bfwg_nwg(a)) * ((size_t)9 * d->C1 * d->Cout + d->Cout) * sizeof(float);
 }
 
 void wgrad_reduce_launch(const float* slab_w, const float* slab_b, int ksplit, int ntaps, int Cin, int Cout, int64_t stap, int64_t sk,
@@ -1010,6 +1306,30 @@ int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, 
   a.d = *d;
   a.d.in_fold = nullptr;
   a.dy = dy;
+  const bool xb = d->x_dtype == LVAE_DT_BF16, dyb = d->y_dtype == LVAE_DT_BF16;
+  if (const int nr = bfwg_half_ranges(d, a)) {
+    a.slab_w = static_cast<float*>(workspace);
+    a.slab_b = db ? a.slab_w + (size_t)nr * 9 * d->C1 * d->Cout : nullptr;
+    const size_t qlds = (size_t)2 * (a.halo_px + 128) * BFH_LDK * 2;
+    static const hipError_t attr = [] {
+      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16h_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16h_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16h_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+      return e;
+    }();
+    if (attr != hipSuccess) {
+      set_error("conv3x3_wgrad_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(attr));
+      return (int)attr;
+    }
+    const dim3 qgrid(2 * nr);
+    if (xb && dyb) hipLaunchKernelGGL((conv3x3_wgrad_bf16h_kernel<true, true>), qgrid, dim3(512), qlds, s, a);
+    else if (dyb) hipLaunchKernelGGL((conv3x3_wgrad_bf16h_kernel<false, true>), qgrid, dim3(512), qlds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16h_kernel<true, false>), qgrid, dim3(512), qlds, s, a);
+    LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16h");
+    wgrad_reduce_launch(a.slab_w, a.slab_b, nr, 9, d->C1, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
+    LVAE_LAUNCH_CHECK("conv3x3_wgrad_bf16_reduce");
+    return 0;
+  }
   const int nwg = bfwg_nwg(a);
   a.slab_w = static_cast<float*>(workspace);
   a.slab_b = db ? a.slab_w + (size_t)nwg * 9 * d->C1 * d->Cout : nullptr;
@@ -1017,7 +1337,6 @@ int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, 
   if (lds < 32 * 64 * 4) lds = 32 * 64 * 4;
   const dim3 grid(nwg, (d->Cout + 63) / 64);
   if (lds < 64 * 64 * 4) lds = 64 * 64 * 4;   // bias-gradient reduction of the 8-channel mapping
-  const bool xb = d->x_dtype == LVAE_DT_BF16, dyb = d->y_dtype == LVAE_DT_BF16;
   const bool c8ok = d->C1 % 8 == 0 && d->Cout % 8 == 0;
   if (dyb && c8ok && xb) {
     if (a.bm == 128) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<2, 1, true, true>), grid, dim3(512), lds, s, a);

@@ -812,7 +812,8 @@ def test_conv1x1_gate_bwd_fused_bf16_operands(K, shape):
     assert rel(db.cpu() - db0, db_ref.float()) < 5e-6
 
 
-@pytest.mark.parametrize('case', [(256, 64, 64, 16, 16), (33, 64, 64, 32, 32), (300, 64, 64, 8, 8), (70, 32, 64, 16, 16), (40, 64, 100, 32, 32)])
+@pytest.mark.parametrize('case', [(256, 64, 64, 16, 16), (33, 64, 64, 32, 32), (300, 64, 64, 8, 8), (70, 32, 64, 16, 16), (40, 64, 100, 32, 32),
+                                  (301, 64, 64, 16, 16), (1025, 64, 64, 8, 8), (67, 64, 64, 32, 32)])   # quadrant form: ragged ranges, a half-empty last tile
 def test_conv3x3_wgrad_bf16_operands(K, case):
     """Weight / bias gradient with bf16 matrix-core operands (transposed LDS reads, persistent accumulators): against the fp64 sum
     over operands that were rounded to bf16 beforehand, accumulating into non-zero gradient buffers; fused BN+ELU prologue."""
