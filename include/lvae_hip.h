@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 14
+#define LVAE_ABI_VERSION 15
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -125,7 +125,7 @@ typedef struct lvae_conv_desc {
   int64_t workspace_bytes; /* lvae_conv2d_workspace(d) bytes enable every kernel variant; fewer select a variant needing none */
   int32_t workspace_ready; /* non-zero: `workspace` already holds this descriptor's transformed weights (written by
                               lvae_conv2d_prepare_weights after the last change of w); the launch skips its own transform */
-  float* stats_out;       /* NULL, or [lvae_conv2d_stats_rows(d)][2][Cout]: per-workgroup partial BatchNorm statistics of the
+  float* stats_out;       /* NULL, or [lvae_conv2d_stats_buffer_rows(d)][2][Cout]: per-workgroup partial BatchNorm statistics of the
                               OUTPUT y: (sum(y - pivot), sum((y - pivot)^2)) per channel, for lvae_bn_finalize_parts_f32 */
   const float* stats_pivot; /* [Cout] pivot of those sums (e.g. the running mean of the BatchNorm that consumes y) */
   /* stats_mode = LVAE_STATS_BN_BWD: y is the gradient dh w.r.t. h = act(x*scale + shift) of a training-mode BatchNorm; the
@@ -178,6 +178,11 @@ int32_t lvae_conv2d_stats_rows(const lvae_conv_desc* d);
 /* 1 when the variant selected for `d` also stores its pivot behind the partial rows (stats_out then needs rows + 1 rows) and can
  * itself consume such a buffer through d->in_parts (the position-major kernel of the <= 4x4 levels); 0 otherwise. */
 int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d);
+/* Rows to ALLOCATE for d->stats_out: lvae_conv2d_stats_rows(d), plus one when the selected variant stores its pivot row behind them
+ * (stats_mode LVAE_STATS_BN_FWD and lvae_conv2d_folds_bn_finalize, asked on the descriptor without its in_fold); 0 when there is no
+ * statistics epilogue. Size the buffer
+ * from this, read the partial rows [0, lvae_conv2d_stats_rows(d)). */
+int32_t lvae_conv2d_stats_buffer_rows(const lvae_conv_desc* d);
 
 /* Batched weight pre-transform: one launch for every convolution of a training step instead of one per convolution call.
  * For each descriptor with lvae_conv2d_workspace(d) > 0 give it a PRIVATE scratch buffer in d->workspace (kept until the

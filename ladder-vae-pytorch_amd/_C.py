@@ -59,7 +59,7 @@ class RbExt(C.Structure):
 RB_PRO_AFFINE, RB_PRO_BN_APPLY, RB_PRO_GATE_BWD = 0, 1, 2
 RB_EPI_PLAIN, RB_EPI_GATE = 0, 1
 
-ABI_VERSION = 14  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 15  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     'lvae_conv2d_variant': (_I, [C.POINTER(ConvDesc)]),
     'lvae_resblock_bf16_storage': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_folds_bn_finalize': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_conv2d_stats_buffer_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_prepare_entry_bytes': (_Z, []),
     'lvae_conv2d_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_prepare_weights': (C.c_int, [_P, _I, _I, _P]),

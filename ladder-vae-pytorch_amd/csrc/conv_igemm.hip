@@ -445,6 +445,16 @@ extern "C" int32_t lvae_conv2d_folds_bn_finalize(const lvae_conv_desc* d) {
   return (v == LVAE_VARIANT_WINO_F32 || v == LVAE_VARIANT_WINO_SIX) && conv3x3_wino_folds(d) ? 1 : 0;
 }
 
+extern "C" int32_t lvae_conv2d_stats_buffer_rows(const lvae_conv_desc* d) {
+  if (d == nullptr) return 0;
+  const int32_t rows = lvae_conv2d_stats_rows(d);
+  if (rows <= 0) return 0;
+  if (d->stats_mode != LVAE_STATS_BN_FWD) return rows;  // BatchNorm-backward sums have no pivot
+  lvae_conv_desc t = *d;  // the pivot row depends on the kernel choice, which is made on the descriptor without its fold
+  t.in_fold = nullptr;
+  return rows + (lvae_conv2d_folds_bn_finalize(&t) != 0 ? 1 : 0);
+}
+
 extern "C" int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv2d_f32");
   if (rc) return rc;

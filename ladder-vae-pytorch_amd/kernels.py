@@ -322,9 +322,9 @@ def conv2d(x, weight, g, bias=None, x2=None, in_scale=None, in_shift=None, in_ac
     if stats_pivot is not None:
         rows = lib.lvae_conv2d_stats_rows(C.byref(d))
         if rows > 0:
-            piv_row = bool(lib.lvae_conv2d_folds_bn_finalize(C.byref(d)))
-            buf = torch.empty((rows + int(piv_row), 2, g.Cout), dtype=torch.float32, device=x.device)
-            parts = StatParts(buf, rows, piv_row)
+            buf_rows = lib.lvae_conv2d_stats_buffer_rows(C.byref(d))   # + 1 where the kernel stores its pivot behind the partial rows
+            buf = torch.empty((buf_rows, 2, g.Cout), dtype=torch.float32, device=x.device)
+            parts = StatParts(buf, rows, buf_rows > rows)
             d.stats_out, d.stats_pivot = ptr(buf), ptr(stats_pivot)
     call('lvae_conv2d_f32', C.byref(d), stream_ptr())
     del fold

@@ -145,6 +145,10 @@ def test_folded_bn_finalize_agrees_with_the_finalize_launch_on_random_shapes(K):
         y1, parts = K.conv2d(x, w1, g1, stats_pivot=pivot)
         if parts is None:
             continue
+        # the ABI's allocation rule: lvae_conv2d_stats_buffer_rows = partial rows (+ the pivot row where the kernel stores one)
+        assert parts.buf.shape[0] == parts.rows + int(parts.has_pivot) and parts.buf[parts.rows:].shape[0] == int(parts.has_pivot)
+        if parts.has_pivot:
+            assert torch.equal(parts.buf[parts.rows, 0], pivot)
         M = N * H * W
         bn_a, bn_b = bn(), bn()
         ya, _, coef_a = K.conv2d(y1, w2, g2, in_act='elu', in_bn=(parts, pivot, bn_a))
