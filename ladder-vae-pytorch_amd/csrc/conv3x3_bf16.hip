@@ -283,20 +283,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
       const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
       // the BatchNorm input rows of the backward sums are requested BEFORE the first store of this pass: a wave's memory counter retires in
       // order, so a load issued behind a write-through store waits for that store's trip to memory (conv3x3_wino.hip, round 4)
-      f32x4 sx0[BM / 32], sx1[BM / 32];
-      if (bwd && d.stats_out) {
+      // (all rows requested in one go — a dtype branch per row made each row its own round trip — and the Dropout2d mask rows with them:
+      // loaded between the stores they were three more dependent round trips, `load; s_waitcnt vmcnt(0)` each)
+      f32x4 sx0[BM / 32], sx1[BM / 32], mk0[BM / 32], mk1[BM / 32];
+      bf16x8 sxq[BM / 32];
+      const bool want_sx = bwd && d.stats_out;
+      if (want_sx && sxbf) {
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) {
+          const int p = p0 + 32 * q, pc = p < nvalid ? p : 0;
+          sxq[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.stats_x) + (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col);
+        }
+      } else if (want_sx) {
 #pragma unroll
         for (int q = 0; q < BM / 32; ++q) {
           const int p = p0 + 32 * q, pc = p < nvalid ? p : 0;
           const size_t xo = (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col;
-          if (sxbf) {
-            const bf16x8 xq = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(d.stats_x) + xo);
-            sx0[q] = f32x4{(float)xq[0], (float)xq[1], (float)xq[2], (float)xq[3]};
-            sx1[q] = f32x4{(float)xq[4], (float)xq[5], (float)xq[6], (float)xq[7]};
-          } else {
-            sx0[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo);
-            sx1[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo + 4);
-          }
+          sx0[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo);
+          sx1[q] = *reinterpret_cast<const f32x4*>(d.stats_x + xo + 4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < BM / 32; ++q) {
+        const int p = p0 + 32 * q, pc = p < nvalid ? p : 0;
+        mk0[q] = mk1[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (d.out_scale) {
+          const int n = n0 + fastdiv(pc, a.m_thw);
+          mk0[q] = *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
+          mk1[q] = *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col + 4);
+        }
+      }
+      if (want_sx && sxbf) {
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) {
+          sx0[q] = f32x4{(float)sxq[q][0], (float)sxq[q][1], (float)sxq[q][2], (float)sxq[q][3]};
+          sx1[q] = f32x4{(float)sxq[q][4], (float)sxq[q][5], (float)sxq[q][6], (float)sxq[q][7]};
         }
       }
 #pragma unroll
@@ -304,13 +325,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
         const int p = p0 + 32 * q;
         if (p < nvalid) {
           f32x4 v[2];
-          v[0] = *reinterpret_cast<const f32x4*>(Os + p * LDO + c8) + bias[0];
-          v[1] = *reinterpret_cast<const f32x4*>(Os + p * LDO + c8 + 4) + bias[1];
-          if (d.out_scale) {
-            const int n = n0 + fastdiv(p, a.m_thw);
-            v[0] = v[0] * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
-            v[1] = v[1] * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col + 4);
-          }
+          v[0] = (*reinterpret_cast<const f32x4*>(Os + p * LDO + c8) + bias[0]) * mk0[q];
+          v[1] = (*reinterpret_cast<const f32x4*>(Os + p * LDO + c8 + 4) + bias[1]) * mk1[q];
           v[0] = act_fwd4(v[0], d.out_act);
           v[1] = act_fwd4(v[1], d.out_act);
           const bf16x8 o = to_bf16x8(v[0], v[1]);
@@ -374,23 +390,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
     const bool ybf = d.y_dtype == LVAE_DT_BF16, sxbf = d.stats_x_dtype == LVAE_DT_BF16;
     const float* op = Os + p0 * LDO + c4;
     const int nvalid = min(tile_px, (d.N - n0) * a.TH * a.TW);
-    f32x4 sxr[BM / 16];   // BatchNorm input rows of the backward sums, requested before the first store of the pass (see above)
+    f32x4 sxr[BM / 16], mkr[BM / 16];   // BatchNorm input rows of the backward sums and the mask rows, requested before the first store of the pass (see above)
+    if (d.stats_mode == LVAE_STATS_BN_BWD && d.stats_out) {
+      if (sxbf) {
+#pragma unroll
+        for (int q = 0; q < BM / 16; ++q) {
+          const int p = p0 + 16 * q, pc = p < nvalid ? p : 0;
+          sxr[q] = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col, true);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < BM / 16; ++q) {
+          const int p = p0 + 16 * q, pc = p < nvalid ? p : 0;
+          sxr[q] = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col, false);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BM / 16; ++q) {
+      const int p = p0 + 16 * q, pc = p < nvalid ? p : 0;
+      mkr[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (d.out_scale) mkr[q] = *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(n0 + fastdiv(pc, a.m_thw)) * d.Cout + col);
+    }
+    // consumed before the first store too: rows only used under `p < nvalid` stay pending on the path that skips them, and hipcc then drains
+    // the whole counter (the stores with it) when their registers are reused in a later row
+#pragma unroll
+    for (int q = 0; q < BM / 16; ++q) asm volatile("" ::"v"(mkr[q]));
     if (d.stats_mode == LVAE_STATS_BN_BWD && d.stats_out) {
 #pragma unroll
-      for (int q = 0; q < BM / 16; ++q) {
-        const int p = p0 + 16 * q, pc = p < nvalid ? p : 0;
-        sxr[q] = load4_dt(d.stats_x, (size_t)((n0 * d.H + oh0) * d.W + pc) * d.Cout + col, sxbf);
-      }
+      for (int q = 0; q < BM / 16; ++q) asm volatile("" ::"v"(sxr[q]));
     }
 #pragma unroll
     for (int q = 0; q < BM / 16; ++q) {
       const int p = p0 + 16 * q;
       if (p < nvalid) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias;
-        if (d.out_scale) {
-          const int n = n0 + fastdiv(p, a.m_thw);
-          v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)n * d.Cout + col);
-        }
+        f32x4 v = (*reinterpret_cast<const f32x4*>(op + q * 16 * LDO) + bias) * mkr[q];
         v = act_fwd4(v, d.out_act);
         store4_dt(d.y, ybase + (size_t)q * 16 * d.Cout, v, ybf);
         if (d.stats_mode == LVAE_STATS_BN_BWD) {
