@@ -1,4 +1,5 @@
-"""Aggregate a rocprofv3 kernel_trace.csv by (kernel, grid) — helper for reading profiles."""
+"""Aggregate a rocprofv3 kernel_trace.csv by (kernel, grid) — helper for reading profiles.
+python tools/prof_agg.py <kernel_trace.csv> 0 <rows> [last-step]   (last-step: only the launches of the last replayed training step)"""
 import collections
 import csv
 import re
@@ -6,6 +7,13 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if len(sys.argv) > 4 and sys.argv[4] == 'last-step':
+    # exactly one replayed training step: the launches behind the second-to-last Adamax launch up to and including the last one
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    opt = [i for i, r in enumerate(rows) if 'adamax_kernel' in r['Kernel_Name']]
+    rows = rows[opt[-2] + 1:opt[-1] + 1]
+    print('# one replayed step: %d launches, %.3f ms from the first start to the last end' %
+          (len(rows), (int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp'])) / 1e6))
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     name = r['Kernel_Name']

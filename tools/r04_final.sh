@@ -1,5 +1,5 @@
 # Round-4 measurement set, all on ONE box so that the numbers agree with each other:
-#   1. rocprofv3 --kernel-trace --stats of the bench command (fp32)   -> r04_kernel_by_grid.txt (+ rocprofv3's own kernel_stats CSV)
+#   1. rocprofv3 --kernel-trace --stats of the bench command (fp32)   -> r04_kernel_by_grid.txt, r04_last_step_by_grid.txt (one replayed step) (+ rocprofv3's own kernel_stats CSV)
 #   2. the same for --dtype bf16                                       -> r04_bf16_kernel_by_grid.txt
 #   3. step-level PMC passes (eager step), fp32 and bf16                -> r04_pmc/hbm_traffic.json, hbm_traffic_bf16.json
 #   4. fused residual-block kernels: phase stamps, per-level chain times, whole-step A/B (fused vs one kernel per op)
@@ -14,6 +14,7 @@ bash tools/r04_prof.sh f32 || exit 1
 cp gpurun_out/r04/f32_kernel_by_grid.txt $OUT/r04_kernel_by_grid.txt; cp gpurun_out/r04/f32_kernel_stats.csv $OUT/r04_kernel_stats.csv
 bash tools/r04_prof.sh bf16 --dtype bf16 || exit 1
 cp gpurun_out/r04/bf16_kernel_by_grid.txt $OUT/r04_bf16_kernel_by_grid.txt
+cp gpurun_out/r04/f32_last_step_by_grid.txt $OUT/r04_last_step_by_grid.txt; cp gpurun_out/r04/bf16_last_step_by_grid.txt $OUT/r04_bf16_last_step_by_grid.txt
 bash tools/r04_pmc_step.sh f32 > $OUT/pmc_f32.log 2>&1 || { echo "PMC passes (fp32) failed"; tail -5 $OUT/pmc_f32.log; exit 1; }
 N=$(grep steps_in_run $OUT/pmc_f32.log | cut -d= -f2)
 python tools/pmc_step_json.py gpurun_out/r04_pmc_f32_f/f_counter_collection.csv gpurun_out/r04_pmc_f32_w/w_counter_collection.csv $N $OUT/hbm_traffic.json > $OUT/pmc_summary_f32.txt || exit 1

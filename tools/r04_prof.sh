@@ -9,4 +9,5 @@ CMD="bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --no-bf16-li
 rm -rf /tmp/prof_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o g -- python3 $CMD > gpurun_out/r04/${TAG}_prof.log 2>&1 || exit 1
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04/${TAG}_kernel_stats.csv \;
 { echo "# rocprofv3 --kernel-trace --stats of: python3 $CMD (15 steps in the trace: 2 eager + capture + 12 replays; divide calls by 15 for per-step counts; the ~3.2 k copyBuffer rows are the host->device parameter copies of model construction)"; python tools/prof_agg.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 0 90; } > gpurun_out/r04/${TAG}_kernel_by_grid.txt
+python tools/prof_agg.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 0 200 last-step > gpurun_out/r04/${TAG}_last_step_by_grid.txt
 tail -2 gpurun_out/r04/${TAG}_prof.log
