@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LVAE_ABI_VERSION 15
+#define LVAE_ABI_VERSION 16
 
 #define LVAE_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define LVAE_EALIGN (-2)   /* pointer / channel count not aligned as the vector path requires */
@@ -315,6 +315,20 @@ int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, f
  * kernel (anything but 3x3 / stride 1 / <= 64 input channels / >= 16384 pixels) run in fp32. */
 int lvae_conv2d_wgrad_bf16(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Which kernel family lvae_conv2d_wgrad_f32 (and the grouped call) runs for `d` (d->x_dtype / y_dtype = the storage types of x / dy):
+ * diagnostics for the parity tests and the profiles. */
+enum {
+  LVAE_WGRAD_VARIANT_GENERIC = 0,   /* fp32 MFMA, generic implicit GEMM (strided / transposed / odd channel counts) */
+  LVAE_WGRAD_VARIANT_IMG = 1,       /* whole-image tiles of the H*W <= 64 levels on the bf16 matrix pipe: six exact bf16-piece products per fp32
+                                       product (LVAE_PREC_F32) or bf16 operands (LVAE_PREC_BF16); 3x3 (<= 64 -> <= 64 channels) and 1x1
+                                       (<= 64 -> <= 128), up to 32 gradients per launch (csrc/conv_wgrad_img.hip, round 5) */
+  LVAE_WGRAD_VARIANT_BF16 = 2,      /* 3x3, bf16 operands, >= 16384 pixels (whole-slab or half-slab form) */
+  LVAE_WGRAD_VARIANT_WINO = 3,      /* Winograd-domain fp32 MFMA (large 3x3 layers) */
+  LVAE_WGRAD_VARIANT_DIRECT_1X1 = 4,/* 1x1 at >= 32 k pixels straight from memory */
+  LVAE_WGRAD_VARIANT_TILE = 5,      /* stride-1 "same" 3x3 / 1x1 on LDS-resident tiles, fp32 MFMA, wave-specialised */
+  LVAE_WGRAD_VARIANT_THIN = 6       /* stems: one workgroup per image, vector ALU */
+};
+int32_t lvae_conv2d_wgrad_variant(const lvae_conv_desc* d);
 /* n independent weight gradients (descs[i], dy[i], dw[i], db[i]; db[i] may be NULL): same results as n calls of
  * lvae_conv2d_wgrad_f32 in index order. The low-resolution levels of the ladder fill 16-64 CUs per gradient and depend on
  * nothing but their own inputs, so launches that share a kernel variant go out together (up to 12 per launch, one grouped

@@ -16,6 +16,7 @@ GATHER_CONV, GATHER_TRANSPOSED = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 DT_F32, DT_BF16 = 0, 1
 VARIANT_DIRECT, VARIANT_POS, VARIANT_WINO_F32, VARIANT_WINO_SIX, VARIANT_BF16_DIRECT, VARIANT_SIX_DIRECT = 0, 2, 3, 4, 5, 6
+WGRAD_VARIANT_GENERIC, WGRAD_VARIANT_IMG, WGRAD_VARIANT_BF16, WGRAD_VARIANT_WINO, WGRAD_VARIANT_DIRECT_1X1, WGRAD_VARIANT_TILE, WGRAD_VARIANT_THIN = range(7)
 FORM_AUTO, FORM_F32_MFMA, FORM_SIX_PRODUCT, FORM_SIX_PRODUCT_DIRECT = 0, 1, 2, 3
 
 
@@ -59,7 +60,7 @@ class RbExt(C.Structure):
 RB_PRO_AFFINE, RB_PRO_BN_APPLY, RB_PRO_GATE_BWD = 0, 1, 2
 RB_EPI_PLAIN, RB_EPI_GATE = 0, 1
 
-ABI_VERSION = 15  # LVAE_ABI_VERSION of include/lvae_hip.h
+ABI_VERSION = 16  # LVAE_ABI_VERSION of include/lvae_hip.h
 
 _P, _I, _L, _F, _Z, _U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     'lvae_conv2d_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_bf16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
+    'lvae_conv2d_wgrad_variant': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_wgrad_grouped_workspace': (_Z, [C.POINTER(ConvDesc), _I]),
     'lvae_conv2d_wgrad_grouped_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),

@@ -9,6 +9,7 @@
 // fixed order (bitwise reproducible, no float atomics) and accumulates into the gradient arena.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "lvae_common.h"
@@ -384,6 +385,12 @@ void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s) {
 }
 
 size_t conv_wgrad_wino_workspace(const lvae_conv_desc* d);
+// whole-image tiles of the <= 8x8 levels on the bf16 matrix pipe (conv_wgrad_img.hip): up to 32 gradients per launch
+size_t conv_wgrad_img_workspace(const lvae_conv_desc* d);
+int conv_wgrad_img_kind(const lvae_conv_desc* d);
+int conv_wgrad_img_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
+                           void* const* workspace, int n, int kind, hipStream_t s);
+int conv_wgrad_img_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 size_t conv3x3_wgrad_bf16_workspace(const lvae_conv_desc* d);
 int conv3x3_wgrad_bf16_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
 int conv_wgrad_wino_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
@@ -496,6 +503,8 @@ using namespace lvae;
 
 extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   if (!d) return 0;
+  const size_t img = conv_wgrad_img_workspace(d);   // fp32-stored operands of the <= 8x8 levels, either precision
+  if (img) return img;
   const size_t bf = conv3x3_wgrad_bf16_workspace(d);   // precision = LVAE_PREC_BF16 descriptors that have a bf16 weight-gradient kernel
   if (bf) return bf;
   const size_t wino = conv_wgrad_wino_workspace(d);
@@ -512,6 +521,17 @@ extern "C" size_t lvae_conv2d_wgrad_workspace(const lvae_conv_desc* d) {
   return (size_t)ksplit * per * sizeof(float);
 }
 
+extern "C" int32_t lvae_conv2d_wgrad_variant(const lvae_conv_desc* d) {
+  if (!d) return LVAE_WGRAD_VARIANT_GENERIC;
+  if (conv_wgrad_img_workspace(d)) return LVAE_WGRAD_VARIANT_IMG;
+  if (conv3x3_wgrad_bf16_workspace(d)) return LVAE_WGRAD_VARIANT_BF16;
+  if (conv_wgrad_wino_workspace(d)) return LVAE_WGRAD_VARIANT_WINO;
+  if (conv1x1_wgrad_workspace(d)) return LVAE_WGRAD_VARIANT_DIRECT_1X1;
+  if (conv_wgrad_tile_workspace(d)) return LVAE_WGRAD_VARIANT_TILE;
+  if (thin_wgrad_workspace(d)) return LVAE_WGRAD_VARIANT_THIN;
+  return LVAE_WGRAD_VARIANT_GENERIC;
+}
+
 extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   int rc = conv_desc_check(d, "lvae_conv2d_wgrad_f32");
@@ -520,6 +540,10 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE,
                "lvae_conv2d_wgrad_f32: workspace %zu < %zu", workspace_bytes, lvae_conv2d_wgrad_workspace(d));
   static const bool halo_off = tune("LVAE_DISABLE_HALO", 0) != 0;
+  if (!halo_off && conv_wgrad_img_workspace(d)) {
+    const int hr = conv_wgrad_img_try(d, dy, dw, db, workspace, (hipStream_t)stream);
+    if (hr != -1000) return hr;
+  }
   if (!halo_off && conv3x3_wgrad_bf16_workspace(d)) {
     const int hr = conv3x3_wgrad_bf16_try(d, dy, dw, db, workspace, (hipStream_t)stream);
     if (hr != -1000) return hr;
@@ -620,29 +644,39 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     ws[i] = wp;
     wp += (lvae_conv2d_wgrad_workspace(&descs[i]) + 255) / 256 * 256;
     const bool al = (reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0;
-    const bool bf16 = !halo_off && conv3x3_wgrad_bf16_workspace(&descs[i]) != 0;   // launched one by one (lvae_conv2d_wgrad_f32 below)
-    const bool wino = !halo_off && !bf16 && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
-    const bool groupable = !halo_off && !wino && !bf16 && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
+    const int img = !halo_off && al ? conv_wgrad_img_kind(&descs[i]) : -1;   // kinds 100 + ...: whole-image tiles (conv_wgrad_img.hip)
+    const bool bf16 = !halo_off && img < 0 && conv3x3_wgrad_bf16_workspace(&descs[i]) != 0;   // launched one by one (lvae_conv2d_wgrad_f32 below)
+    const bool wino = !halo_off && img < 0 && !bf16 && al && conv_wgrad_wino_workspace(&descs[i]) != 0;
+    const bool groupable = !halo_off && img < 0 && !wino && !bf16 && al && descs[i].Cout % 4 == 0 && (descs[i].C1 + descs[i].C2) % 4 == 0 &&
                            conv1x1_wgrad_workspace(&descs[i]) == 0;
     // kinds 0-4: tile kernel variants; 5-7: Winograd kernel for W = 8 / 16 / 32 (grouped only while one problem leaves CUs idle)
     static const int64_t wino_group_max = tune("LVAE_WINO_GROUP_MAX_M", 65536);
-    kind[i] = wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < wino_group_max ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
-                   : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1);
+    kind[i] = img >= 0 ? 100 + img
+                       : (wino ? ((int64_t)descs[i].N * descs[i].H * descs[i].W < wino_group_max ? (descs[i].W == 8 ? 5 : (descs[i].W == 16 ? 6 : 7)) : -1)
+                               : (groupable ? conv_wgrad_tile_kind(&descs[i]) : -1));
   }
   std::vector<char> done(n, 0);
-  for (int k = 0; k < 8; ++k) {
-    const lvae_conv_desc* gd[12];
-    const float* gy[12];
-    float* gw[12];
-    float* gb[12];
-    void* gs[12];
-    int idx[12];
+  std::vector<int> kinds;   // the distinct kinds present, ascending
+  for (int i = 0; i < n; ++i)
+    if (kind[i] >= 0 && std::find(kinds.begin(), kinds.end(), kind[i]) == kinds.end()) kinds.push_back(kind[i]);
+  std::sort(kinds.begin(), kinds.end());
+  for (int k : kinds) {
+    constexpr int kCap = 32;
+    const int cap = k >= 100 ? kCap : 12;
+    const lvae_conv_desc* gd[kCap];
+    const float* gy[kCap];
+    float* gw[kCap];
+    float* gb[kCap];
+    void* gs[kCap];
+    int idx[kCap];
     int m = 0;
     auto flush = [&]() -> int {
       if (m == 0) return 0;
-      int rc = m == 1 ? -1000
-                      : (k >= 5 ? conv_wgrad_wino_grouped(gd, gy, gw, gb, gs, m, (hipStream_t)stream)
-                                : conv_wgrad_tile_grouped(gd, gy, gw, gb, gs, m, k, (hipStream_t)stream));
+      int rc;
+      if (k >= 100) rc = conv_wgrad_img_grouped(gd, gy, gw, gb, gs, m, k - 100, (hipStream_t)stream);   // (one problem too: the same kernel)
+      else rc = m == 1 ? -1000
+                       : (k >= 5 ? conv_wgrad_wino_grouped(gd, gy, gw, gb, gs, m, (hipStream_t)stream)
+                                 : conv_wgrad_tile_grouped(gd, gy, gw, gb, gs, m, k, (hipStream_t)stream));
       if (rc == 0)
         for (int j = 0; j < m; ++j) done[idx[j]] = 1;
       m = 0;
@@ -651,7 +685,7 @@ extern "C" int lvae_conv2d_wgrad_grouped_f32(const lvae_conv_desc* descs, const 
     for (int i = 0; i < n; ++i) {
       if (kind[i] != k) continue;
       gd[m] = &descs[i]; gy[m] = dy[i]; gw[m] = dw[i]; gb[m] = db[i]; gs[m] = ws[i]; idx[m] = i;
-      if (++m == 12) {
+      if (++m == cap) {
         int rc = flush();
         if (rc) return rc;
       }

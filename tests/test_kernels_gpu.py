@@ -843,6 +843,51 @@ def test_conv3x3_wgrad_bf16_operands(K, case):
     assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 1e-5    # the bias gradient sums the unrounded dy
 
 
+IMG_WGRAD_CASES = [
+    # N, Cin, Cout, H, W, k: the <= 8x8 levels' weight gradients on whole-image tiles (csrc/conv_wgrad_img.hip)
+    (256, 64, 64, 8, 8, 3), (256, 64, 64, 4, 4, 3), (256, 64, 64, 2, 2, 3),      # as in the CIFAR-15 step: 64 / 16 / 4 slabs
+    (37, 64, 64, 4, 4, 3), (50, 32, 64, 2, 2, 3), (3, 64, 64, 8, 8, 3), (1, 64, 64, 2, 2, 3),   # ragged last tile, thin input, one image
+    (21, 64, 48, 4, 8, 3), (19, 24, 64, 8, 4, 3),                                # non-square images, channel counts below 64
+    (256, 64, 128, 8, 8, 1), (77, 64, 128, 4, 4, 1), (130, 64, 128, 2, 2, 1), (9, 48, 100, 4, 4, 1),   # GateLayer2d's 1x1 (64 -> 128)
+]
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', IMG_WGRAD_CASES)
+def test_conv_wgrad_whole_image_tiles(K, case, prec):
+    """lvae_conv2d_wgrad_f32 on the whole-image-tile kernel (transposed LDS reads, six-product / bf16 operands, persistent accumulators,
+    fixed-order slab reduce) against the float64 sum: fused BatchNorm + ELU prologue (3x3), accumulation into non-zero buffers."""
+    N, Ci, Co, H, W, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, k // 2)
+    kw = {}
+    xin = x
+    if k == 3:
+        sc, sh = 1 + 0.1 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+        kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_act='elu')
+        xin = F.elu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    rnd = (lambda t: t.bfloat16().double()) if prec == 'bf16' else (lambda t: t.double())
+    xin64 = rnd(xin).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    F.conv2d(xin64, w64, None, padding=k // 2).backward(rnd(dy))
+    dw0, db0 = torch.randn(Co, Ci, k, k, generator=g) * 0.1, torch.randn(Co, generator=g)
+    dw, db = packed_weight(dw0), db0.cuda()
+    K.set_precision(prec)
+    try:
+        d = K._desc(geom, wp, nhwc(x), None, N, H, W, H, W, Co, geom.s_ci, geom.s_co, K.GATHER_CONV)
+        assert K._C.load().lvae_conv2d_wgrad_variant(ctypes.byref(d)) == K._C.WGRAD_VARIANT_IMG
+        K.conv2d_wgrad(nhwc(x), nhwc(dy), wp, geom, dw, db, **kw)
+    finally:
+        K.set_precision('f32')
+    tol = 3e-4 if prec == 'bf16' else 3e-6   # bf16: rounding boundaries of the GPU's fast-exp ELU vs the CPU's
+    assert rel(dw.cpu() - dw0, w64.grad.float()) < tol
+    assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 3e-6   # the bias gradient sums the unrounded dy
+
+
 @pytest.mark.parametrize('nmix', [1, 5, 10, 16, 20])
 def test_dmol_any_component_count_matches_oracle(K, nmix):
     """DiscretizedLogisticMixLikelihood(n_components) of lib/likelihoods.py:183-202 takes any count (the reference only ever builds 10):
