@@ -219,10 +219,31 @@ int lvae_conv1x1_gate_bwd_f32(const lvae_conv_desc* d, const float* dout, const 
  * never written to memory; y [M,64] is the convolution input the forward saved. Deterministic (per-workgroup partial slabs in
  * `workspace`, summed in a fixed order). lvae_conv1x1_gate_bwd_wgrad_workspace(d) == 0: shape not supported (needs C = 64 and at
  * least 16384 pixels) — use lvae_conv1x1_gate_bwd_f32 + lvae_conv2d_wgrad_f32. */
+/* Deferred BatchNorm-backward apply (round 5; `ap` NULL or ap->parts NULL: none). In a chain of residual blocks the block that ran just
+ * before this one in the backward ends with dx = BN1'(dh; x) + add (lvae_affine_act_bwd_parts_f32), and that dx IS this call's dout. With
+ * `ap` the kernel reduces the partial rows parts [rows][2][64] (written by the producer of dh, stats_mode LVAE_STATS_BN_BWD) itself, forms
+ * dout on the fly from (dh — element type dh_bf16 —, x, add or NULL; coefficient block coef [4][64] = scale, shift, mean, rstd; M = N*H*W),
+ * stores it to out [M][64] (fp32) and accumulates dgamma / dbeta; `dout` is not read. One launch, its finalize launch and one tensor pass
+ * per gated block less. Not with form LVAE_FORM_F32_MFMA. */
+typedef struct lvae_bn_apply {
+  const float* parts;
+  int32_t rows;
+  int32_t act;
+  int64_t M;
+  const float* coef;
+  const float* dh;
+  const float* x;
+  const float* add;
+  float* dgamma;
+  float* dbeta;
+  float* out;
+  int32_t dh_bf16;
+  int32_t reserved_;
+} lvae_bn_apply;
 size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d);
 int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
                                     float* dw, int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, size_t workspace_bytes,
-                                    void* stream);
+                                    const lvae_bn_apply* ap, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused residual-block kernels of the low-resolution levels (H*W a divisor of 64: 8x8, 4x4, 2x2 ...), "whole-image tiles"
@@ -237,7 +258,8 @@ int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, 
  *                                   bwd_coef [4][64], bwd_M = N*H*W, dgamma / dbeta accumulated by workgroup 0 — times the Dropout2d mask
  *                                   pro_drop [N][64]; also stored to xt_out [N,H,W,64] (the weight gradient of the producer reads it)
  *             LVAE_RB_PRO_GATE_BWD  the input of the convolution is the GateLayer2d backward of lvae_conv1x1_gate_bwd_f32: dab from
- *                                   (dout [M][64], ab_in [M][128]) — stored to dab when non-NULL — then (dab . gate_w^T) * pro_drop, stored to xt_out
+ *                                   (dout [M][64], ab_in [M][128]) — stored to dab when non-NULL — then (dab . gate_w^T) * pro_drop, stored to xt_out;
+ *                                   with ap_parts != NULL dout itself is formed in the prologue (deferred BatchNorm-backward apply, see the struct)
  *   epilogue  LVAE_RB_EPI_PLAIN     y = (conv + bias) * out_scale and the statistics epilogue of lvae_conv2d_f32 (stats_out: lvae_resblock_conv_rows(d)
  *                                   rows, plus one pivot row behind them for LVAE_STATS_BN_FWD)
  *             LVAE_RB_EPI_GATE      (forward prologue only) y as above, then lvae_conv1x1_gate_f32 on it inside the same launch: ab [M][128]
@@ -285,6 +307,22 @@ typedef struct lvae_rb_ext {
    * XCD while they wait for their own operands. Speed only: the ranges are read, never interpreted. */
   const void* pf_ptr[2];
   int64_t pf_bytes[2];
+  /* Deferred BatchNorm-backward apply in front of LVAE_RB_PRO_GATE_BWD (round 5; ap_parts == NULL: none). In a chain of residual blocks the
+   * block that ran just before this one in the backward ends with dx = BN1'(dh1; x) + dout (lvae_affine_act_bwd_parts_f32 with `add`), and
+   * that dx IS this launch's dout. Instead of a launch of its own, this prologue forms it from (ap_parts [ap_rows][2][64] written by the
+   * producer of ap_dh, coefficient block ap_coef [4][64], ap_M = N*H*W, ap_dh, ap_x, ap_add — all required), accumulates ap_dgamma / ap_dbeta
+   * (workgroup 0) and stores it to ap_out [M][64]; `dout` is not read. */
+  const float* ap_parts;
+  int32_t ap_rows;
+  int32_t ap_act;
+  int64_t ap_M;
+  const float* ap_coef;
+  const float* ap_dh;
+  const float* ap_x;
+  const float* ap_add;
+  float* ap_dgamma;
+  float* ap_dbeta;
+  float* ap_out;
 } lvae_rb_ext;
 /* Pre-split copy of a gate weight for lvae_resblock_conv_f32: `g` describes the 1x1 convolution in the direction it is used (forward:
  * C1 = 64, Cout = 128, w_sk / w_sn = strides of the input / gate channel; backward: C1 = 128, Cout = 64, strides swapped); only C1, Cout, w,

@@ -47,6 +47,13 @@ class BnFold(C.Structure):
                 ('coef_out', C.c_void_p)]
 
 
+class BnApply(C.Structure):
+    """mirror of struct lvae_bn_apply"""
+    _fields_ = [('parts', C.c_void_p), ('rows', C.c_int32), ('act', C.c_int32), ('M', C.c_int64), ('coef', C.c_void_p), ('dh', C.c_void_p),
+                ('x', C.c_void_p), ('add', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('out', C.c_void_p),
+                ('dh_bf16', C.c_int32), ('reserved_', C.c_int32)]
+
+
 class RbExt(C.Structure):
     """mirror of struct lvae_rb_ext"""
     _fields_ = [('prologue', C.c_int32), ('epilogue', C.c_int32), ('gate_w', C.c_void_p), ('gate_w_sk', C.c_int64), ('gate_w_sn', C.c_int64),
@@ -54,7 +61,10 @@ class RbExt(C.Structure):
                 ('out_stats', C.c_void_p), ('out_stats_pivot', C.c_void_p), ('dout', C.c_void_p), ('ab_in', C.c_void_p), ('dab', C.c_void_p),
                 ('bwd_parts', C.c_void_p), ('bwd_rows', C.c_int32), ('bwd_act', C.c_int32), ('bwd_M', C.c_int64), ('bwd_coef', C.c_void_p),
                 ('bwd_x', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('pro_drop', C.c_void_p), ('xt_out', C.c_void_p),
-                ('pf_ptr', C.c_void_p * 2), ('pf_bytes', C.c_int64 * 2)]
+                ('pf_ptr', C.c_void_p * 2), ('pf_bytes', C.c_int64 * 2),
+                ('ap_parts', C.c_void_p), ('ap_rows', C.c_int32), ('ap_act', C.c_int32), ('ap_M', C.c_int64), ('ap_coef', C.c_void_p),
+                ('ap_dh', C.c_void_p), ('ap_x', C.c_void_p), ('ap_add', C.c_void_p), ('ap_dgamma', C.c_void_p), ('ap_dbeta', C.c_void_p),
+                ('ap_out', C.c_void_p)]
 
 
 RB_PRO_AFFINE, RB_PRO_BN_APPLY, RB_PRO_GATE_BWD = 0, 1, 2
@@ -83,7 +93,7 @@ SIGNATURES = {
     'lvae_conv1x1_gate_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv1x1_gate_bwd_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
     'lvae_conv1x1_gate_bwd_wgrad_workspace': (_Z, [C.POINTER(ConvDesc)]),
-    'lvae_conv1x1_gate_bwd_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _L, _L, _P, _P, _Z, _P]),
+    'lvae_conv1x1_gate_bwd_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _L, _L, _P, _P, _Z, C.POINTER(BnApply), _P]),
     'lvae_resblock_gate_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_resblock_gate_prepare_entry': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_resblock_conv_rows': (_I, [C.POINTER(ConvDesc)]),

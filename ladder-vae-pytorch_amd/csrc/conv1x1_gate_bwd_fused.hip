@@ -43,6 +43,7 @@ struct GbfArgs {
   float* slab_b;       // [nwg][128] or null
   int M, ohw, ntiles, act;
   int in_bf16, dx_bf16;  // storage of ab and y (lvae_conv_desc.x_dtype) and of dx (y_dtype); dout is fp32. bf16-operand kernel only.
+  lvae_bn_apply ap;      // deferred BatchNorm-backward apply that produces dout (ap.parts == nullptr: dout is given)
 };
 
 constexpr int GB_LDA = 132;  // dab / weight row pitch (floats): conflict-free ds_read_b128 (as conv1x1.hip)
@@ -196,11 +197,15 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
 // them with the transposing ds_read_b64_tr_b16 (bf16_frag.h), as conv3x3_wgrad_bf16_kernel does.
 constexpr int GBB_LDA = 136;  // dab row pitch in bf16 (128 channels + 8: 272 bytes, 16-byte multiples for ds_read_b128)
 constexpr int GBB_LDY = 72;   // y row pitch in bf16
-constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4; }
+constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4 + 6 * 64 * 4; }
 
 // S16 (SPLIT == 1): ab, y and dx are bf16-stored (residual-block internals under compute_dtype bf16) and move as 16-byte pieces: a thread
 // takes 8 channels of ONE pixel row per tile (5 loads of 16 bytes instead of 8, one 16-byte store instead of two of 8).
-template <int SPLIT, bool S16 = false>
+// AP (round 5): dout is not given but is the result of the BatchNorm-backward apply that ends the backward of the residual block that ran
+// just before (its input is this block's output): dout = BN'(ap.dh; ap.x) + ap.add. The persistent workgroups reduce the producer's
+// partial rows once (fixed order), then form dout while they stage a tile and store it to ap.out (this block's own last apply reads it as
+// its `add`); workgroup 0 accumulates dgamma / dbeta. Saves the apply launch, its finalize launch and one 16.8 MB pass per gated block.
+template <int SPLIT, bool S16 = false, bool AP = false>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
   kernarg_warmup<sizeof(GbfArgs)>();
   static_assert(SPLIT == 1 || !S16, "bf16 storage exists for the bf16-operand form only");
@@ -209,10 +214,57 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [SPLIT][64 px][136]: dab tile
   __bf16* Ys = As + SPLIT * A_PLANE;                                 // [SPLIT][64 px][72]: y tile
   float* Os = reinterpret_cast<float*>(Ys + SPLIT * Y_PLANE);        // [64 px][68]: dx staging (fp32)
+  float* Cf = Os + 64 * GB_LDY;                                      // [6][64]: scale, shift, mean, rstd, mean(g), mean(g xhat) of the deferred apply
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool wg_role = wave >= 4;  // waves 4-7: weight gradient; waves 0-3: dgrad
   const int wm = (wave & 3) >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5, G = lane >> 4, i16 = lane & 15;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  if (AP) {
+    // the producer's partial rows [rows][2][64], summed by 16 row groups (8 independent 16-byte loads in flight per thread), then in double
+    const int q = t & 31, rg = t >> 5, rows = a.ap.rows;
+    f32x4 acc = zero4;
+    for (int r = rg; r < rows; r += 16 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = r + 16 * u;
+        v[u] = *reinterpret_cast<const f32x4*>(a.ap.parts + (size_t)(rr < rows ? rr : 0) * 128 + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + 16 * u < rows) acc += v[u];
+    }
+    *reinterpret_cast<f32x4*>(Os + rg * 128 + q * 4) = acc;   // [16][128] <= the staging tile
+    if (t < 256) Cf[t] = a.ap.coef[t];
+    __syncthreads();
+    if (t < 64) {
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        sa += (double)Os[g * 128 + t];
+        sb += (double)Os[g * 128 + 64 + t];
+      }
+      Cf[256 + t] = (float)(sa / (double)a.ap.M);
+      Cf[320 + t] = (float)(sb / (double)a.ap.M);
+      if (blockIdx.x == 0) {
+        if (a.ap.dbeta) a.ap.dbeta[t] += (float)sa;
+        if (a.ap.dgamma) a.ap.dgamma[t] += (float)sb;
+      }
+    }
+    __syncthreads();
+  }
+  // dout[m][c .. c + 3] of the deferred apply from (dh, x, add) and the coefficient rows in LDS
+  auto ap_value = [&](const f32x4 dh, const f32x4 xv, const f32x4 ad, int c) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(Cf + c), sh = *reinterpret_cast<const f32x4*>(Cf + 64 + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(Cf + 128 + c), rs = *reinterpret_cast<const f32x4*>(Cf + 192 + c);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cf + 256 + c), c2 = *reinterpret_cast<const f32x4*>(Cf + 320 + c);
+    const f32x4 u = xv * sc + sh;
+    f32x4 g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = dh[j] * act_grad(u[j], a.ap.act);
+    return (g - c1 - (xv - mu) * rs * c2) * sc + ad;
+  };
 
   // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s, SPLIT pieces
   bf16x8 breg[8][SPLIT];
@@ -231,16 +283,27 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
 
   constexpr int IT = S16 ? 1 : 2;
   f32x4 pg[2], pa[IT], pb[IT], py[IT];
+  f32x4 px[AP ? 2 : 1], pd[AP ? 2 : 1];   // deferred apply: x and add rows (pg then holds dh)
   bf16x8 qa, qb, qy;   // S16: ab[c8 .. c8 + 7], ab[64 + c8 ..], y[c8 ..] of row r8
   const int c4 = (t & 15) * 4, r0 = t >> 4;
   const int c8 = (t & 7) * 8, r8 = t >> 3;
+  const bool ap_add = AP && a.ap.add != nullptr, ap_dh_bf = AP && a.ap.dh_bf16 != 0;
   auto prefetch = [&](int tile) {
     const int m0 = tile * 64;
     if (S16) {
       const int m = m0 + r8;
       const size_t mc = m < a.M ? (size_t)m : 0;
+      if (AP) {
+        pg[0] = load4_dt(a.ap.dh, mc * 64 + c8, ap_dh_bf);
+        pg[1] = load4_dt(a.ap.dh, mc * 64 + c8 + 4, ap_dh_bf);
+        px[0] = *reinterpret_cast<const f32x4*>(a.ap.x + mc * 64 + c8);
+        px[1] = *reinterpret_cast<const f32x4*>(a.ap.x + mc * 64 + c8 + 4);
+        pd[0] = ap_add ? *reinterpret_cast<const f32x4*>(a.ap.add + mc * 64 + c8) : zero4;
+        pd[1] = ap_add ? *reinterpret_cast<const f32x4*>(a.ap.add + mc * 64 + c8 + 4) : zero4;
+      } else {
       pg[0] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c8);
       pg[1] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c8 + 4);
+      }
       qa = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.ab) + mc * 128 + c8);
       qb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.ab) + mc * 128 + 64 + c8);
       qy = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.y) + mc * 64 + c8);
@@ -250,6 +313,11 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
     for (int u = 0; u < IT; ++u) {
       const int m = m0 + r0 + 32 * u;
       const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
+      if (AP) {
+        pg[u] = load4_dt(a.ap.dh, mc * 64 + c4, ap_dh_bf);
+        px[u] = *reinterpret_cast<const f32x4*>(a.ap.x + mc * 64 + c4);
+        pd[u] = ap_add ? *reinterpret_cast<const f32x4*>(a.ap.add + mc * 64 + c4) : zero4;
+      } else
       pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
       pa[u] = load4_dt(a.ab, mc * 128 + c4, a.in_bf16 != 0);
       pb[u] = load4_dt(a.ab, mc * 128 + 64 + c4, a.in_bf16 != 0);
@@ -279,6 +347,13 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       f32x4 lo[2] = {zero4, zero4}, hi[2] = {zero4, zero4};
       bf16x8 yv = {0, 0, 0, 0, 0, 0, 0, 0};
       if (m0 + r8 < a.M) {
+        if (AP) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            pg[h] = ap_value(pg[h], px[h], pd[h], c8 + 4 * h);
+            store_wt4(a.ap.out + (size_t)(m0 + r8) * 64 + c8 + 4 * h, pg[h]);
+          }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -303,6 +378,10 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       const int r = r0 + 32 * u;
       f32x4 lo = zero4, hi = zero4, yv = zero4;
       if (m0 + r < a.M) {
+        if (AP) {
+          pg[u] = ap_value(pg[u], px[u], pd[u], c4);
+          store_wt4(a.ap.out + (size_t)(m0 + r) * 64 + c4, pg[u]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float sg = sigmoidf_(pb[u][j]);
@@ -451,9 +530,14 @@ size_t conv1x1_gate_bwd_fused_workspace(const lvae_conv_desc* d) {
 }
 
 int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int act, float* dw,
-                           int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, hipStream_t s) {
+                           int64_t dw_sk, int64_t dw_sn, float* db, void* workspace, const lvae_bn_apply* ap, hipStream_t s) {
   if (!al16f(dout) || !al16f(ab) || !al16f(y) || !al16f(d->w) || !al16f(d->y) || !al16f(d->out_scale) || !al16f(workspace)) return -1000;
   GbfArgs a;
+  a.ap = lvae_bn_apply{};
+  if (ap != nullptr && ap->parts != nullptr) {
+    if (!al16f(ap->parts) || !al16f(ap->coef) || !al16f(ap->dh) || !al16f(ap->x) || !al16f(ap->add) || !al16f(ap->out)) return -1000;
+    a.ap = *ap;
+  }
   a.dout = dout;
   a.ab = ab;
   a.y = y;
@@ -483,21 +567,33 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     attr_set = true;
   }
   const bool f32_mfma = d->form == LVAE_FORM_F32_MFMA;  // default for fp32: the six-product form on the bf16 MFMA
+  const bool with_ap = a.ap.parts != nullptr;
+  if (with_ap && (f32_mfma && d->precision != LVAE_PREC_BF16)) {
+    set_error("conv1x1_gate_bwd_fused: the deferred BatchNorm-backward apply exists in the bf16-matrix-pipe kernels only (not with LVAE_FORM_F32_MFMA)");
+    return LVAE_EINVAL;
+  }
   if (d->precision == LVAE_PREC_BF16) {
-    if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
+    if (with_ap) {
+      if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
+      else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, false, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
+    } else if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
     else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, false>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
   } else if (!f32_mfma) {
     static std::atomic<bool> attr3_set{false};
     if (!attr3_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
       if (e != hipSuccess) {
         set_error("conv1x1_gate_bwd_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return (int)e;
       }
       attr3_set = true;
     }
-    hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
+    if (with_ap) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false, true>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
+    else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
   } else {
     hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
   }
@@ -516,14 +612,18 @@ extern "C" size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d)
 
 extern "C" int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
                                                float* dw, int64_t dw_sk, int64_t dw_sn, float* db, void* workspace,
-                                               size_t workspace_bytes, void* stream) {
-  LVAE_REQUIRE(d && dout && ab && y && d->y && dw && workspace, LVAE_EINVAL, "lvae_conv1x1_gate_bwd_wgrad_f32: null pointer");
+                                               size_t workspace_bytes, const lvae_bn_apply* ap, void* stream) {
+  const bool with_ap = ap != nullptr && ap->parts != nullptr;
+  LVAE_REQUIRE(d && (dout || with_ap) && ab && y && d->y && dw && workspace, LVAE_EINVAL, "lvae_conv1x1_gate_bwd_wgrad_f32: null pointer");
+  if (with_ap)
+    LVAE_REQUIRE(ap->rows > 0 && ap->M == (int64_t)d->N * d->H * d->W && ap->coef && ap->dh && ap->x && ap->out, LVAE_EINVAL,
+                 "lvae_conv1x1_gate_bwd_wgrad_f32: deferred apply needs parts / rows, M = N*H*W, the coefficient block, dh, x and out");
   const size_t need = conv1x1_gate_bwd_fused_workspace(d);
   LVAE_REQUIRE(need > 0, LVAE_EINVAL,
                "lvae_conv1x1_gate_bwd_wgrad_f32: unsupported shape (needs the gate of a 64-channel block: 1x1, 128 -> 64 dgrad view, at "
                "least 16384 pixels); use lvae_conv1x1_gate_bwd_f32 + lvae_conv2d_wgrad_f32");
   LVAE_REQUIRE(workspace_bytes >= need, LVAE_EWORKSPACE, "lvae_conv1x1_gate_bwd_wgrad_f32: workspace %zu < %zu", workspace_bytes, need);
-  const int rc = conv1x1_gate_bwd_fused(d, dout, ab, y, act, dw, dw_sk, dw_sn, db, workspace, (hipStream_t)stream);
+  const int rc = conv1x1_gate_bwd_fused(d, dout, ab, y, act, dw, dw_sk, dw_sn, db, workspace, ap, (hipStream_t)stream);
   LVAE_REQUIRE(rc != -1000, LVAE_EALIGN, "lvae_conv1x1_gate_bwd_wgrad_f32: buffers must be 16-byte aligned");
   return rc;
 }

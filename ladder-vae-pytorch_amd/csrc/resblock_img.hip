@@ -197,9 +197,14 @@ __device__ __forceinline__ void rb_parts_finish(const float* __restrict__ parts,
 // ELU: every activation id the launch uses is LVAE_ACT_ELU (the model's default), known at compile time. With a run-time id each of the
 // kernel's ~40 four-value activation calls is a chain of scalar compares and TAKEN branches, and with one wave per SIMD a taken branch
 // costs a refetch (~20-30 cycles): the staging segment held 172 branch instructions and ran at ~9 cycles per executed instruction.
-template <int SPLIT, int MI, int PRO, int EPI, bool ELU>
+// AP (PRO_GATE_BWD only): the launch's dout does not exist yet — it is the result of the BatchNorm-backward apply that ends the backward
+// of the block that ran just before (that block's input IS this block's output), deferred into this prologue: dout = BN'(ap_dh; ap_x) +
+// ap_add from the partial sums ap_parts, formed on the fly and stored to ap_out (this block's own final apply reads it as its `add`).
+// One launch (7-8.6 us of a dependent chain) per residual block less.
+template <int SPLIT, int MI, int PRO, int EPI, bool ELU, bool AP = false>
 __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   static_assert(MI == 1, "64-pixel tiles");
+  static_assert(!AP || PRO == LVAE_RB_PRO_GATE_BWD, "the deferred apply feeds the gate-backward prologue");
   constexpr int BM = 64, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
   constexpr int OS_BYTES = BM * LDO * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   const lvae_conv_desc& d = a.d;
   const lvae_rb_ext& e = a.e;
   const int in_act = ELU ? LVAE_ACT_ELU : d.in_act, stats_act = ELU ? LVAE_ACT_ELU : d.stats_act;
-  const int gate_act = ELU ? LVAE_ACT_ELU : e.act, bwd_act = ELU ? LVAE_ACT_ELU : e.bwd_act;
+  const int gate_act = ELU ? LVAE_ACT_ELU : e.act, bwd_act = ELU ? LVAE_ACT_ELU : e.bwd_act, ap_act = ELU ? LVAE_ACT_ELU : e.ap_act;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int bid = blockIdx.x;
@@ -247,25 +252,37 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   RB_STAMP(0);
   // ---- L2 warm-up for the NEXT launch. Every convolution of a step has weights of its own, so the 221 KB a workgroup streams are cold in
   // its XCD's L2 when its kernel starts (in-step the launches measured ~4 us longer than back to back on one layer): the workgroups of an
-  // XCD (round-robin placement: speed only) touch one word of every 128-byte line of the ranges the next launch will stream. The touches
-  // are inline-asm loads into registers that nothing reads: written as C++ loads whose values are summed, hipcc waited for each of them
-  // in turn (an s_waitcnt per touch, i.e. a full HBM round trip each, at the very start of the kernel: 6.8 us of phase 0-8 in
-  // tools/rb_stamps_instep.py). The compiler does not count these loads in its s_waitcnt arithmetic; the counter retires in order, so its
-  // waits can only become stricter, never too weak. The destination registers stay reserved until the drain at the end of the kernel.
+  // XCD (round-robin placement: speed only) touch one word of every 128-byte line of the ranges the next launch will stream.
+  // The touches are plain (volatile) loads whose values are consumed by an empty asm at the END of the prologue (pf_drain): the compiler
+  // tracks them like any load, so their registers cannot be handed to another value while a touch is in flight. (Round 4 issued them from
+  // inline asm with "=v" outputs that the compiler believed written at once; under the register pressure of a new variant of this kernel
+  // hipcc split such a live range, the late-landing load overwrote the register's next owner — an address — and the step died with a
+  // memory access fault: profiles/r05_faults/. The memory counter retires in order, so by the time the prologue has consumed its own
+  // operand rows — requested BEHIND the touches — the touches have landed and the drain costs no wait.) Summing the values into a dummy
+  // right away, the first form of round 4, made hipcc wait for each touch in turn (6.8 us of serialized HBM round trips).
+  // Issued behind rb_parts_issue where a prologue has partial rows to reduce: those are L2-resident and needed first.
   constexpr int PFN = 6;   // touches per lane and range: 6 x 256 lanes x 128 B = 192 KB of a range per workgroup at most
   unsigned pf_dump[2][PFN];
+  auto pf_issue = [&]() {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int per_xcd = (a.nwg + 7) >> 3, part = bid >> 3;
-    const int lines = e.pf_ptr[k] != nullptr ? (int)((e.pf_bytes[k] + 127) >> 7) : 0, per = (lines + per_xcd - 1) / per_xcd;
-    const int lo = part * per, hi = min(lo + per, lines);
-    const char* base = static_cast<const char*>(e.pf_ptr[k]) + (size_t)(lo + t) * 128;   // ranges are far below 2 GB: 32-bit line arithmetic
+    for (int k = 0; k < 2; ++k) {
+      const int per_xcd = (a.nwg + 7) >> 3, part = bid >> 3;
+      const int lines = e.pf_ptr[k] != nullptr ? (int)((e.pf_bytes[k] + 127) >> 7) : 0, per = (lines + per_xcd - 1) / per_xcd;
+      const int lo = part * per, hi = min(lo + per, lines);
+      const char* base = static_cast<const char*>(e.pf_ptr[k]) + (size_t)(lo + t) * 128;   // ranges are far below 2 GB: 32-bit line arithmetic
 #pragma unroll
-    for (int i = 0; i < PFN; ++i) {
-      pf_dump[k][i] = 0;
-      if (lo + t + 256 * i < hi) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dump[k][i]) : "v"(base + i * 256 * 128) : "memory");
+      for (int i = 0; i < PFN; ++i) {
+        pf_dump[k][i] = 0;
+        if (lo + t + 256 * i < hi) pf_dump[k][i] = *reinterpret_cast<const unsigned*>(base + i * 256 * 128);
+      }
     }
-  }
+  };
+  auto pf_drain = [&]() {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < PFN; ++i) asm volatile("" ::"v"(pf_dump[k][i]));
+  };
 
   // ---- this thread's four rows: patch position, image, global row (rows past the batch read row 0 and are masked)
   int hp[NQ], img_n[NQ];
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     // finalize then runs while the interior is still in flight
     f32x4 pv[RB_PF];
     if (f.parts != nullptr) rb_parts_issue(f.parts, f.rows, pv);
+    pf_issue();
     const bool lead = t < 64 && f.parts != nullptr;
     const float pivot = lead ? f.parts[((size_t)f.rows * 2) * 64 + t] : 0.f;  // the producer's pivot, stored behind its partial rows
     const float gam = lead && f.gamma ? f.gamma[t] : 1.f, bet = lead && f.beta ? f.beta[t] : 0.f;
@@ -370,6 +388,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     // small L2-resident things first (partial rows, coefficients, accumulators), the cold operand rows behind them (in-order memory counter)
     f32x4 pv[RB_PF];
     rb_parts_issue(e.bwd_parts, e.bwd_rows, pv);
+    pf_issue();
     const f32x4 sc = *reinterpret_cast<const f32x4*>(e.bwd_coef + c4), sh = *reinterpret_cast<const f32x4*>(e.bwd_coef + 64 + c4);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(e.bwd_coef + 128 + c4), rs = *reinterpret_cast<const f32x4*>(e.bwd_coef + 192 + c4);
     const bool acc_here = bid == 0 && t < 64;
@@ -411,11 +430,51 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     __bf16* Ds = reinterpret_cast<__bf16*>(mainr);
     constexpr int LDD = RB_LDD, d_plane = BM * LDD;
     f32x4 go[NQ], aa[NQ], bb[NQ], dm[NQ];
+    if (AP) {
+      // small L2-resident things first (partial rows, coefficients, accumulators), the cold operand rows behind them (in-order memory counter)
+      f32x4 pv[RB_PF];
+      rb_parts_issue(e.ap_parts, e.ap_rows, pv);
+      pf_issue();
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(e.ap_coef + c4), sh = *reinterpret_cast<const f32x4*>(e.ap_coef + 64 + c4);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(e.ap_coef + 128 + c4), rs = *reinterpret_cast<const f32x4*>(e.ap_coef + 192 + c4);
+      const bool acc_here = bid == 0 && t < 64;
+      const float db0 = acc_here && e.ap_dbeta ? e.ap_dbeta[t] : 0.f, dg0 = acc_here && e.ap_dgamma ? e.ap_dgamma[t] : 0.f;
+      f32x4 xa[NQ], ad[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      go[q] = *reinterpret_cast<const f32x4*>(e.dout + grow[q] * 64 + c4);
-      aa[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + c4);
-      bb[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + 64 + c4);
+      for (int q = 0; q < NQ; ++q) {
+        go[q] = *reinterpret_cast<const f32x4*>(e.ap_dh + grow[q] * 64 + c4);
+        xa[q] = *reinterpret_cast<const f32x4*>(e.ap_x + grow[q] * 64 + c4);
+        ad[q] = *reinterpret_cast<const f32x4*>(e.ap_add + grow[q] * 64 + c4);   // (required: a conditional load costs a full s_waitcnt in the emitted code)
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        aa[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + c4);
+        bb[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + 64 + c4);
+      }
+      rb_parts_finish(e.ap_parts, e.ap_rows, pv, scr, [&](int c, double sa, double sb) {
+        scr[1024 + c] = (float)(sa / (double)e.ap_M);
+        scr[1024 + 64 + c] = (float)(sb / (double)e.ap_M);
+        if (bid == 0) {
+          if (e.ap_dbeta) e.ap_dbeta[c] = db0 + (float)sa;
+          if (e.ap_dgamma) e.ap_dgamma[c] = dg0 + (float)sb;
+        }
+      });
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(scr + 1024 + c4), c2 = *reinterpret_cast<const f32x4*>(scr + 1024 + 64 + c4);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 g = go[q] * rb_act_grad4(xa[q] * sc + sh, ap_act);
+        const f32x4 v = (g - c1 - (xa[q] - mu) * rs * c2) * sc + ad[q];
+        go[q] = v;
+        if (ok[q]) store_wt4(e.ap_out + grow[q] * 64 + c4, v);
+      }
+    } else {
+      pf_issue();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        go[q] = *reinterpret_cast<const f32x4*>(e.dout + grow[q] * 64 + c4);
+        aa[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + c4);
+        bb[q] = *reinterpret_cast<const f32x4*>(e.ab_in + grow[q] * 128 + 64 + c4);
+      }
     }
     // gate weights in the transposed use (pre-split planes [k-step 8][column tile 2][plane][lane][8]): this wave's 32 output columns
     bf16x8 gq[8][SPLIT];
@@ -484,6 +543,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     zero_ring();
   }
 
+  pf_drain();   // the prologue has consumed operand rows requested behind the touches: they have landed (in-order counter), their registers are free
   // ---- everything the epilogue reads from memory is requested now; it arrives while the matrix cores work
   f32x4 ep_bias = zero4, ep_mask[NQ], ep_piv = zero4, ep_bsh = zero4, ep_bmu = zero4, ep_brs = zero4, ep_sx[NQ], ep_res[NQ], ep_ga = zero4, ep_gb = zero4;
   const bool plain_stats = EPI == LVAE_RB_EPI_PLAIN && d.stats_out != nullptr;
@@ -715,12 +775,6 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       if (bid == 0 && which == 0 && stats_fwd) stats_out[((size_t)a.nwg * 2) * 64 + c] = stats_pivot[c];
     }
   }
-  // the warm-up touches have long landed; drain the counter before their registers are released
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int i = 0; i < PFN; ++i) asm volatile("" ::"v"(pf_dump[k][i]));
   RB_STAMP(7);
 #ifdef LVAE_RB_DBG_REPS
   }
@@ -801,9 +855,9 @@ static bool rb_plan(const lvae_conv_desc* d, RbArgs& a, int& mi) {
   return rb_lds_bytes(rb_split(d), mi, a.halo_px, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_GATE) <= 160 * 1024;
 }
 
-template <int SPLIT, int MI, int PRO, int EPI, bool ELU>
+template <int SPLIT, int MI, int PRO, int EPI, bool ELU, bool AP = false>
 static int rb_launch(const RbArgs& a, hipStream_t s) {
-  auto kern = rb_conv_kernel<SPLIT, MI, PRO, EPI, ELU>;
+  auto kern = rb_conv_kernel<SPLIT, MI, PRO, EPI, ELU, AP>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -825,6 +879,7 @@ static bool rb_all_elu(const RbArgs& a) {
   const auto elu = [](int act) { return act == LVAE_ACT_ELU; };
   if (e.prologue == LVAE_RB_PRO_AFFINE && (d.in_scale != nullptr || a.f.parts != nullptr) && !elu(d.in_act)) return false;
   if (e.prologue == LVAE_RB_PRO_BN_APPLY && !elu(e.bwd_act)) return false;
+  if (e.prologue == LVAE_RB_PRO_GATE_BWD && e.ap_parts != nullptr && !elu(e.ap_act)) return false;
   if ((e.prologue == LVAE_RB_PRO_GATE_BWD || e.epilogue == LVAE_RB_EPI_GATE) && !elu(e.act)) return false;
   if (d.stats_out != nullptr && d.stats_mode == LVAE_STATS_BN_BWD && !elu(d.stats_act)) return false;
   return true;
@@ -836,6 +891,7 @@ static int rb_dispatch2(const RbArgs& a, hipStream_t s) {
   if (pro == LVAE_RB_PRO_AFFINE) return epi == LVAE_RB_EPI_GATE ? rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_GATE, ELU>(a, s)
                                                                   : rb_launch<SPLIT, MI, LVAE_RB_PRO_AFFINE, LVAE_RB_EPI_PLAIN, ELU>(a, s);
   if (pro == LVAE_RB_PRO_BN_APPLY) return rb_launch<SPLIT, MI, LVAE_RB_PRO_BN_APPLY, LVAE_RB_EPI_PLAIN, ELU>(a, s);
+  if (a.e.ap_parts != nullptr) return rb_launch<SPLIT, MI, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_PLAIN, ELU, true>(a, s);
   return rb_launch<SPLIT, MI, LVAE_RB_PRO_GATE_BWD, LVAE_RB_EPI_PLAIN, ELU>(a, s);
 }
 
@@ -952,8 +1008,15 @@ extern "C" int lvae_resblock_conv_f32(const lvae_conv_desc* d, const lvae_rb_ext
                  LVAE_EINVAL, "lvae_resblock_conv_f32: BatchNorm-apply prologue needs x (= dh), bwd_x, bwd_parts / rows / M and the coefficient block, 16-byte aligned");
   }
   if (pro == LVAE_RB_PRO_GATE_BWD) {
-    LVAE_REQUIRE(e.dout && e.ab_in && al16r(e.dout) && al16r(e.ab_in) && al16r(e.dab), LVAE_EINVAL,
-                 "lvae_resblock_conv_f32: gate-backward prologue needs dout and ab_in (16-byte aligned tensors)");
+    LVAE_REQUIRE((e.dout || e.ap_parts) && e.ab_in && al16r(e.dout) && al16r(e.ab_in) && al16r(e.dab), LVAE_EINVAL,
+                 "lvae_resblock_conv_f32: gate-backward prologue needs dout (or the deferred apply that produces it) and ab_in (16-byte aligned tensors)");
+    if (e.ap_parts != nullptr) {
+      LVAE_REQUIRE(e.ap_rows > 0 && e.ap_M > 0 && e.ap_coef && e.ap_dh && e.ap_x && e.ap_add && e.ap_out && al16r(e.ap_parts) && al16r(e.ap_coef) &&
+                       al16r(e.ap_dh) && al16r(e.ap_x) && al16r(e.ap_add) && al16r(e.ap_out),
+                   LVAE_EINVAL, "lvae_resblock_conv_f32: deferred apply needs ap_parts / ap_rows / ap_M, the coefficient block, ap_dh, ap_x, ap_add and ap_out, 16-byte aligned");
+    }
+  } else {
+    LVAE_REQUIRE(e.ap_parts == nullptr, LVAE_EINVAL, "lvae_resblock_conv_f32: the deferred apply goes with the gate-backward prologue");
   }
   if (pro == LVAE_RB_PRO_GATE_BWD || epi == LVAE_RB_EPI_GATE) {
     lvae_conv_desc g = lvae_conv_desc{};   // the gate convolution in the direction this launch uses it

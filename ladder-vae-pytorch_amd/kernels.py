@@ -378,9 +378,25 @@ def conv1x1_gate_bwd(dout, ab, weight, g, act, out_scale=None):
     return dab, dx
 
 
-def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scale=None, out_bf16=False):
+def gate_bwd_fused_ok(x_like, weight, g, dweight=None):
+    """True when conv1x1_gate_bwd_wgrad takes the gate convolution (weight, g) on tensors shaped like x_like (N,H,W,C) — and can therefore
+    also form its dout from a deferred BatchNorm-backward apply (PendingApply)."""
+    N, H, W, Cn = x_like.shape
+    if not (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cout == 2 * Cn and g.s_co == 1):
+        return False
+    if dweight is not None and tuple(dweight.stride()) != tuple(weight.stride()):
+        return False
+    if form == _C.FORM_F32_MFMA and precision != PREC_BF16:
+        return False
+    d = _desc(g, weight, x_like, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED)
+    d.C1 = g.Cout
+    return bool(_C.load().lvae_conv1x1_gate_bwd_wgrad_workspace(C.byref(d)))
+
+
+def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scale=None, out_bf16=False, apply=None):
     """conv1x1_gate_bwd and the weight / bias gradient of the gate convolution in one persistent kernel (dab never leaves LDS):
-    returns dx, and accumulates into dweight / dbias. Returns None when the shape is not supported (caller composes the two)."""
+    returns dx, and accumulates into dweight / dbias. Returns None when the shape is not supported (caller composes the two).
+    apply (PendingApply): dout does not exist yet; the kernel forms it from the deferred BatchNorm-backward apply and stores it to apply.out."""
     _chk_nhwc(dout, 'dout')
     N, H, W, Cn = dout.shape
     if not (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and g.Cout == 2 * Cn and g.s_co == 1):
@@ -392,11 +408,15 @@ def conv1x1_gate_bwd_wgrad(dout, ab, y, weight, g, act, dweight, dbias, out_scal
     dx = torch.empty((N, H, W, g.Cin), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dout.device)
     d = _desc(g, weight, ab, None, N, H, W, H, W, g.Cin, g.s_co, g.s_ci, GATHER_TRANSPOSED, out_scale=out_scale, y=dx)
     need = _C.load().lvae_conv1x1_gate_bwd_wgrad_workspace(C.byref(d))
-    if not need:
+    if not need or (apply is not None and form == _C.FORM_F32_MFMA and precision != PREC_BF16):
         return None
     ws = workspace(need, dout.device)
+    ap = None
+    if apply is not None:
+        ap = _C.BnApply(ptr(apply.parts), apply.parts.shape[0], ACT[apply.act], N * H * W, ptr(apply.coef0), ptr_dt(apply.dh), ptr(apply.x),
+                        ptr(apply.add), ptr(apply.dgamma), ptr(apply.dbeta), ptr(apply.out), int(apply.dh.dtype == torch.bfloat16), 0)
     call('lvae_conv1x1_gate_bwd_wgrad_f32', C.byref(d), ptr(dout), ptr_dt(ab), ptr_dt(y), ACT[act], ptr(dweight), g.s_ci, g.s_co, ptr(dbias),
-         ws.data_ptr(), ws.numel(), stream_ptr())
+         ws.data_ptr(), ws.numel(), C.byref(ap) if ap is not None else None, stream_ptr())
     return dx
 
 
@@ -578,9 +598,19 @@ def _rb_bn_bwd(d, bn_bwd, dx):
     return parts
 
 
-def rb_gate_dgrad(dout, ab, gate_w, gate_g, act, drop, weight, g, bn_bwd, prefetch=None):
+class PendingApply:
+    """A BatchNorm-backward apply that its block did NOT launch: dx = BN'(dh; x) + add from the partial rows `parts`, to be formed by the
+    first backward launch of the block that consumes dx (the previous block of the chain) and stored to `out` (ops.ResBlockFn)."""
+    __slots__ = ('parts', 'dh', 'x', 'coef0', 'act', 'dgamma', 'dbeta', 'add', 'out')
+
+    def __init__(self, parts, dh, x, coef0, act, dgamma, dbeta, add, out):
+        self.parts, self.dh, self.x, self.coef0, self.act, self.dgamma, self.dbeta, self.add, self.out = parts, dh, x, coef0, act, dgamma, dbeta, add, out
+
+
+def rb_gate_dgrad(dout, ab, gate_w, gate_g, act, drop, weight, g, bn_bwd, prefetch=None, apply=None):
     """Backward of rb_conv_gate up to the block's second BatchNorm in one launch: dab = gate'(dout, ab), dy2 = (dab . Wg^T) * drop,
-    dh2 = dgrad3x3(dy2) with the BatchNorm-backward sums of bn_bwd = (y1, coef block row 0, act). Returns (dab, dy2, dh2, parts)."""
+    dh2 = dgrad3x3(dy2) with the BatchNorm-backward sums of bn_bwd = (y1, coef block row 0, act). Returns (dab, dy2, dh2, parts).
+    apply (PendingApply): dout does not exist yet; the launch forms it in its prologue and stores it to apply.out (= dout's memory)."""
     N, H, W, Cn = dout.shape
     dev = dout.device
     dab = torch.empty_like(ab)
@@ -592,6 +622,10 @@ def rb_gate_dgrad(dout, ab, gate_w, gate_g, act, drop, weight, g, bn_bwd, prefet
     _rb_gate_ws(e, gate_w, gate_g, dev, True)
     e.act = ACT[act]
     e.dout, e.ab_in, e.dab, e.pro_drop, e.xt_out = ptr(dout), ptr(ab), ptr(dab), ptr(drop), ptr(dy2)
+    if apply is not None:
+        e.ap_parts, e.ap_rows, e.ap_act, e.ap_M = ptr(apply.parts), apply.parts.shape[0], ACT[apply.act], N * H * W
+        e.ap_coef, e.ap_dh, e.ap_x, e.ap_add = ptr(apply.coef0), ptr(apply.dh), ptr(apply.x), ptr(apply.add)
+        e.ap_dgamma, e.ap_dbeta, e.ap_out = ptr(apply.dgamma), ptr(apply.dbeta), ptr(apply.out)
     parts = _rb_bn_bwd(d, bn_bwd, dh)
     _rb_prefetch(e, prefetch)
     call('lvae_resblock_conv_f32', C.byref(d), C.byref(e), stream_ptr())
@@ -626,12 +660,12 @@ def bn_coef_block(scale, shift, mean, rstd):
     return shift.data_ptr() == p0 + n and mean.data_ptr() == p0 + 2 * n and rstd.data_ptr() == p0 + 3 * n
 
 
-def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, dbeta, drop=None, add=None, out_bf16=False):
+def affine_act_bwd_parts(parts, dh, x, scale, shift, act, mean, rstd, dgamma, dbeta, drop=None, add=None, out_bf16=False, out=None):
     """affine_act_bwd (training-mode BatchNorm) with the reduction already done by the epilogue of the convolution that produced dh
-    (conv2d_dgrad(..., bn_bwd=...))."""
+    (conv2d_dgrad(..., bn_bwd=...)). out: write into this tensor instead of a new one."""
     Cn = x.shape[-1]
     M = x.numel() // Cn
-    dx = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    dx = out if out is not None else torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     ws = workspace(8 * Cn, x.device)
     rows_per_n = M // x.shape[0]
     dtypes = _dt(dh) | (_dt(x) << 1) | (_dt(dx) << 2)

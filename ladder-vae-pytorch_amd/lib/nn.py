@@ -214,8 +214,18 @@ class ResidualBlock(nn.Module):
         ent = getattr(x, '_lvae_bn_parts', None)
         if ent is not None and self.training:
             self.__dict__['_in_parts'] = ent
+        # the residual block that produced exactly this tensor object (its only consumer is this block): this block's last backward launch,
+        # the BatchNorm-1 apply, can be left to that block's first backward launch (ops._DEFER_APPLY)
+        src = x.__dict__.pop('_lvae_rb_src', None) if hasattr(x, '__dict__') else None
+        if src is not None and self.training and torch.is_grad_enabled():
+            self.__dict__['_in_src'] = src
+        self.__dict__.pop('_pending_apply', None)   # (left behind by a backward pass that was abandoned)
+        self.__dict__['_accepts_deferred'] = None
         out = ops.ResBlockFn.apply(x, self, m1, m2, self.training, *params)
+        self.__dict__.pop('_in_src', None)
         self.__dict__.pop('_in_parts', None)
+        if self.training and torch.is_grad_enabled() and self.__dict__.get('_accepts_deferred'):
+            out._lvae_rb_src = self
         oparts = self.__dict__.pop('_out_parts', None)
         if oparts is not None:
             out._lvae_bn_parts = oparts

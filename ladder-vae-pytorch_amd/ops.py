@@ -179,6 +179,23 @@ def _rb_next_ranges(direction, blk):
     return nb.__dict__.get('_rb_first_' + direction) if nb is not None else None
 
 
+# The last launch of a residual block's backward is the BatchNorm-1 apply, dx = BN1'(dh1; x) + dout. When the tensor x is exactly the
+# output of the previous residual block of the chain (lib/nn.py hands the producer over with the tensor object, like the BatchNorm
+# partials) and that block's backward starts with a kernel that can form its `dout` itself (the fused gate-backward launches), the apply
+# is not launched: the block returns an unwritten dx and leaves a kernels.PendingApply with the consumer, whose first launch computes dx
+# in its prologue and stores it there. LVAE_DEFER_APPLY=0 (profiling only) keeps the launch.
+_DEFER_APPLY = os.environ.get('LVAE_DEFER_APPLY', '1') != '0'
+_DEFER_LARGE = os.environ.get('LVAE_DEFER_APPLY_LARGE', '1') != '0'   # ... also into the persistent gate-backward kernel of the >= 16x16 levels
+
+
+def _take_pending(blk, dout):
+    pend = blk.__dict__.pop('_pending_apply', None)
+    if pend is not None and pend.out.data_ptr() != dout.data_ptr():
+        raise K._C.LvaeHipError("deferred BatchNorm-backward apply: the gradient that reached the consuming block is not the tensor the "
+                                "producer left unwritten (the block output has another consumer?)")
+    return pend
+
+
 class ResBlockFn(Function):
     """Whole pre-activation residual block ('bacdbacd' / 'bacdbac' recipes of lib/nn.py:64-89, with or without
     BatchNorm, Dropout2d and the gate) as ONE autograd node:
@@ -279,6 +296,12 @@ class ResBlockFn(Function):
         ctx.blk, ctx.training, ctx.s16 = blk, training, s16
         (x0, sc1, sh1, mean1, rstd1), (y1, sc2, sh2, mean2, rstd2) = st
         ctx.rb_bwd = bool(rb_bwd and ab is not None and K.bn_coef_block(sc1, sh1, mean1, rstd1) and K.bn_coef_block(sc2, sh2, mean2, rstd2))
+        ctx.defer_to = blk.__dict__.pop('_in_src', None)
+        acc = 'f32-dh' if ctx.rb_bwd else None   # what the first backward launch of this block can absorb: a deferred apply with an fp32 dh, or any
+        if (not ctx.rb_bwd and _DEFER_LARGE and training and blk.gate is not None and blk.gate.bias is not None and blk.gate.weight.requires_grad and
+                ab is not None and K.gate_bwd_fused_ok(x, blk.gate.weight, blk.gate.geom())):
+            acc = 'any-dh'
+        blk.__dict__['_accepts_deferred'] = acc
         ctx.save_for_backward(x0, y1, y2, ab, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, m1, m2)
         return out
 
@@ -309,6 +332,8 @@ class ResBlockFn(Function):
             blk.__dict__['_out_parts'] = (oparts, pivot)
         ctx.blk, ctx.training, ctx.s16 = blk, True, False
         ctx.rb_bwd = bool(rb_bwd and K.bn_coef_block(*coef1) and K.bn_coef_block(*coef2))
+        ctx.defer_to = blk.__dict__.pop('_in_src', None)
+        blk.__dict__['_accepts_deferred'] = 'f32-dh' if ctx.rb_bwd else None
         ctx.save_for_backward(x, y1, y2, ab, coef1[0], coef1[1], coef1[2], coef1[3], coef2[0], coef2[1], coef2[2], coef2[3], m1, m2)
         return out
 
@@ -326,28 +351,35 @@ class ResBlockFn(Function):
             gw = gate.weight
             _rb_link('bwd', blk, K.rb_weight_ranges(dout, w2, blk.conv2.geom(), True, gate=(gw, gate.geom()), gate_bwd=True))
             dab, dy2, dh2, parts2 = K.rb_gate_dgrad(dout, ab, gw, gate.geom(), act, m2, w2, blk.conv2.geom(), bn_bwd=(y1, sc2, act),
-                                                    prefetch=K.rb_weight_ranges(dout, w1, blk.conv1.geom(), True))
+                                                    prefetch=K.rb_weight_ranges(dout, w1, blk.conv1.geom(), True), apply=_take_pending(blk, dout))
             if gw.requires_grad:
                 wgrad(y2, dab, gw, gate.geom(), grad_buf(gw), grad_buf(gate.bias))
             wgrad(y1, dy2, w2, blk.conv2.geom(), grad_buf(w2), grad_buf(blk.conv2.bias), in_scale=sc2, in_shift=sh2, in_act=act)
             dy1, dh1, parts1 = K.rb_apply_dgrad(parts2, dh2, y1, sc2, act, grad_buf(bn2.weight), grad_buf(bn2.bias), m1, w1, blk.conv1.geom(),
                                                 bn_bwd=(x, sc1, act), prefetch=_rb_next_ranges('bwd', blk))
             wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
-            dx = K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias), add=dout)
+            dx = ResBlockFn._final_apply(ctx, parts1, dh1, x, sc1, sh1, mean1, rstd1, act, bn1, dout)
             return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+        pend = _take_pending(blk, dout)
         if blk.gate is not None:
             gw = blk.gate.weight
             dy2 = None
             if gw.requires_grad and blk.gate.bias is not None:
                 # large levels: gate derivative, dgrad and the gate convolution's weight gradient in one persistent kernel
                 dy2 = K.conv1x1_gate_bwd_wgrad(dout, ab, y2, gw, blk.gate.geom(), act, grad_buf(gw), grad_buf(blk.gate.bias), out_scale=m2,
-                                               out_bf16=s16)
+                                               out_bf16=s16, apply=pend)
+                if dy2 is not None:
+                    pend = None
+            if pend is not None:   # (the fused kernel did not take the shape after all: the apply gets its launch, writing the tensor dout is)
+                pend = ResBlockFn._run_pending(pend)
             if dy2 is None:
                 if s16:
                     raise K._C.LvaeHipError("bf16-stored residual block: the fused gate backward did not take this shape")
                 dab, dy2 = K.conv1x1_gate_bwd(dout, ab, gw, blk.gate.geom(), act, out_scale=m2)
                 wgrad(y2, dab, gw, blk.gate.geom(), grad_buf(gw), grad_buf(blk.gate.bias))
         else:
+            if pend is not None:
+                pend = ResBlockFn._run_pending(pend)
             dy2 = K.scale_rows_add(dout, m2, None) if m2 is not None else dout
         # second half
         w2 = blk.conv2.weight
@@ -376,12 +408,32 @@ class ResBlockFn(Function):
         else:
             dh1 = K.conv2d_dgrad(dy1, w1, blk.conv1.geom(), hw)
         if parts1 is not None:
-            dx = K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias),
-                                        add=dout)
+            dx = ResBlockFn._final_apply(ctx, parts1, dh1, x, sc1, sh1, mean1, rstd1, act, bn1, dout)
         else:
             dx = K.affine_act_bwd(dh1, x, sc1, sh1, act, train1, mean1, rstd1,
                                   grad_buf(bn1.weight) if train1 else None, grad_buf(bn1.bias) if train1 else None, add=dout)
         return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+    @staticmethod
+    def _run_pending(p):
+        """The launch a deferred apply would have been (its consumer could not absorb it after all)."""
+        n = p.coef0.numel()
+        coef = p.coef0.new_empty(0).set_(p.coef0.untyped_storage(), p.coef0.storage_offset(), (4, n), (n, 1))
+        K.affine_act_bwd_parts(p.parts, p.dh, p.x, coef[0], coef[1], p.act, coef[2], coef[3], p.dgamma, p.dbeta, add=p.add, out=p.out)
+        return None
+
+    @staticmethod
+    def _final_apply(ctx, parts1, dh1, x, sc1, sh1, mean1, rstd1, act, bn1, dout):
+        """dx = BN1'(dh1; x) + dout: launched here, or left to the first backward launch of the block that produced x (see _DEFER_APPLY)."""
+        tgt = ctx.defer_to
+        acc = tgt.__dict__.get('_accepts_deferred') if tgt is not None else None
+        if (_DEFER_APPLY and acc is not None and x.dtype == torch.float32 and (dh1.dtype == torch.float32 or acc == 'any-dh') and
+                K.bn_coef_block(sc1, sh1, mean1, rstd1)):
+            dx = torch.empty_like(x)
+            tgt.__dict__['_pending_apply'] = K.PendingApply(parts1, dh1, x, sc1, act, grad_buf(bn1.weight), grad_buf(bn1.bias), dout, dx)
+            return dx
+        return K.affine_act_bwd_parts(parts1, dh1, x, sc1, sh1, act, mean1, rstd1, grad_buf(bn1.weight), grad_buf(bn1.bias), add=dout)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -147,6 +147,66 @@ def test_fused_block_forward_and_backward(K, shape, prec, act):
         K.set_precision('f32')
 
 
+@pytest.mark.parametrize('shape,prec', [((256, 4, 4), 'f32'), ((37, 2, 2), 'f32'), ((64, 8, 8), 'f32'), ((1, 2, 2), 'f32'), ((130, 4, 4), 'bf16'),
+                                        ((256, 16, 16), 'f32'), ((70, 16, 16), 'f32'), ((20, 32, 32), 'f32'), ((257, 16, 16), 'bf16')])
+def test_deferred_batchnorm_apply_in_the_next_blocks_first_backward_launch(K, shape, prec):
+    """The BatchNorm-1 apply that ends a block's backward, dx = BN1'(dh; x) + add, formed instead by the first backward launch of the block
+    that consumes dx (kernels.PendingApply): the whole-image gate-backward + dgrad launch (<= 8x8 levels, lvae_rb_ext.ap_*) and the persistent
+    fused gate-backward kernel (>= 16 k pixels, lvae_bn_apply). Against the two-launch form on the same operands: the deferred launch must
+    write the same dout (to 1e-6: the partial rows are summed in another order), the same dgamma / dbeta, and everything downstream of dout."""
+    N, H, W = shape
+    C = 64
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(11 * N + H)
+    rn = lambda *s_: torch.randn(*s_, generator=g).to(dev)
+    K.set_precision(prec)
+    try:
+        # the producer block's side: dh (gradient w.r.t. act(BN(x))), its partial BatchNorm-backward sums, x, the coefficient block, add
+        x, dh, add = rn(N, H, W, C), rn(N, H, W, C), rn(N, H, W, C)
+        coef = K.bn_stats(x, torch.rand(C, generator=g).to(dev) + 0.5, rn(C) * 0.1, None, None)
+        xh = (x - coef[2]) * coef[3]
+        u = x * coef[0] + coef[1]
+        gg = dh * torch.where(u > 0, torch.ones_like(u), torch.exp(u))
+        rows = 7 if N * H * W < 4096 else 256
+        chunks_g = gg.reshape(-1, C).tensor_split(rows)
+        chunks_x = (gg * xh).reshape(-1, C).tensor_split(rows)
+        parts = torch.stack([torch.stack([a.sum(0), b.sum(0)]) for a, b in zip(chunks_g, chunks_x)]).contiguous()   # [rows][2][C]
+        # the consumer block's side
+        wg = packed_weight(torch.randn(2 * C, C, 1, 1, generator=g) / 8)
+        geg = K.ConvGeom(wg, 1, 0)
+        ab, y2 = rn(N, H, W, 2 * C), rn(N, H, W, C)
+        m2 = ((torch.rand(N, C, generator=g) < 0.8).float() / 0.8).to(dev)
+        dg_a, db_a = torch.full((C,), 0.5, device=dev), torch.full((C,), -1.0, device=dev)
+        dg_b, db_b = dg_a.clone(), db_a.clone()
+        dout = K.affine_act_bwd_parts(parts, dh, x, coef[0], coef[1], 'elu', coef[2], coef[3], dg_a, db_a, add=add)
+        out = torch.full_like(x, float('nan'))   # what the producer would return unwritten
+        pend = K.PendingApply(parts, dh, x, coef[0], 'elu', dg_b, db_b, add, out)
+        if H * W <= 64:
+            w2 = packed_weight(torch.randn(C, C, 3, 3, generator=g) / 24)
+            ge2 = K.ConvGeom(w2, 1, 1)
+            y1 = rn(N, H, W, C)
+            coef2 = K.bn_stats(y1, None, None, None, None)
+            # with L2 warm-up ranges, as inside a step (the first whole-step run of this variant died of late-landing warm-up loads: profiles/r05_faults/)
+            pf = K.rb_weight_ranges(dout, w2, ge2, True, gate=(wg, geg), gate_bwd=True)
+            ref = K.rb_gate_dgrad(dout, ab, wg, geg, 'elu', m2, w2, ge2, bn_bwd=(y1, coef2[0], 'elu'), prefetch=pf)
+            got = K.rb_gate_dgrad(out, ab, wg, geg, 'elu', m2, w2, ge2, bn_bwd=(y1, coef2[0], 'elu'), apply=pend, prefetch=pf)
+        else:
+            assert K.gate_bwd_fused_ok(x, wg, geg)
+            dw_a, dbias_a = torch.zeros_like(wg), torch.zeros(2 * C, device=dev)
+            dw_b, dbias_b = torch.zeros_like(wg), torch.zeros(2 * C, device=dev)
+            ref = (K.conv1x1_gate_bwd_wgrad(dout, ab, y2, wg, geg, 'elu', dw_a, dbias_a, out_scale=m2), dw_a, dbias_a)
+            got = (K.conv1x1_gate_bwd_wgrad(out, ab, y2, wg, geg, 'elu', dw_b, dbias_b, out_scale=m2, apply=pend), dw_b, dbias_b)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all())
+        assert rel(out.cpu(), dout.cpu()) < 1e-6
+        torch.testing.assert_close(dg_b, dg_a, rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(db_b, db_a, rtol=1e-5, atol=1e-4)
+        for a, b in zip(got, ref):
+            assert rel(a.float().cpu(), b.float().cpu()) < (2e-6 if prec == 'f32' else 2e-3)
+    finally:
+        K.set_precision('f32')
+
+
 def test_fused_block_shape_gate(K):
     """lvae_resblock_conv_rows: only 64 -> 64 channel 3x3 / stride 1 / pad 1 layers whose images divide a 64-pixel tile."""
     mk = lambda co, ci, k: packed_weight(torch.randn(co, ci, k, k))
