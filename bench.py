@@ -459,8 +459,8 @@ def main():
     arena = model.pack()
     ldist.broadcast_flat(arena.params)
     opt = Adamax(model, lr=3e-4)
-    allreduce = (ldist.GradAllReduce(arena.grads, segments=arena.segments)
-                 if (world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1') else None)
+    multi = world > 1 or os.environ.get('LVAE_FORCE_DIST') == '1'
+    allreduce = None
     if world > max(1, torch.cuda.device_count()) and not args.no_graph and os.environ.get('LVAE_ALLOW_GLOO_GRAPH') != '1':
         # rehearsal with several ranks on ONE device: two processes replaying multi-thousand-node graphs on one GPU time-slice
         # (2.6x per rank measured); launch eagerly instead
@@ -468,16 +468,32 @@ def main():
         args.no_graph = True
 
     def make_step():
-        return TrainStep(model, opt, use_graph=not args.no_graph, allreduce=allreduce, async_wgrad=args.async_wgrad,
-                         wgrad_streams=args.wgrad_streams, wgrad_group_rows=args.wgrad_group_rows or None)
+        kw = dict(use_graph=not args.no_graph, async_wgrad=args.async_wgrad, wgrad_streams=args.wgrad_streams,
+                  wgrad_group_rows=args.wgrad_group_rows or None)
+        if multi:
+            # more than one rank: both forms of the gradient exchange are built and the faster one ON THIS WORLD SIZE is kept (a few trial
+            # steps of each, all of them real training steps; LVAE_DDP_MODE=split|overlap skips the trial) — engine.AutoExchangeStep
+            from lvae_amd.engine import AutoExchangeStep
+            return AutoExchangeStep(model, opt, arena.grads, arena.segments, trial_steps=3, **kw)
+        return TrainStep(model, opt, **kw)
 
     step = make_step()
+    if multi:
+        allreduce = step.allreduce
     torch.set_num_threads(host_cores())
     ring = [b.to(dev) for b in synth_batches(8, args.batch, 1234 + rank)]
     if rank == 0:
         log('model built (%d params), warming up' % sum(p.numel() for p in model.parameters()))
     for i in range(max(args.warmup, 3)):  # >= 3: two eager steps + the capture replay
         step(ring[i % 8])
+    extra = 0
+    while multi and not step.ready:   # the exchange-form trial (untimed, like the warm-up): 2 x (2 eager + capture + 3 timed) steps at most
+        step(ring[extra % 8])
+        extra += 1
+        if extra > 64:
+            raise SystemExit('the gradient-exchange trial did not finish')
+    if multi:
+        allreduce = step.allreduce
     dt, out = time_steps(step, ring, args.steps, world, dev)
     loss, elbo = float(out['loss']), float(out['elbo'])
     if rank == 0:
@@ -499,6 +515,8 @@ def main():
         }
         if allreduce is not None and allreduce.active:
             line['config']['grad_exchange'] = step.exchange_description()
+            line['config']['grad_exchange_ab'] = {'chosen': getattr(step, 'chosen', None), 'ms_per_step_max_over_ranks': getattr(step, 'timings_ms', None),
+                                                  'trial_steps_untimed_in_this_line': extra}
             line['config']['allreduce_bytes_per_step'] = 4 * arena.grads.numel()
             line['config']['allreduce_buckets'] = len(allreduce.buckets)
             line['config']['allreduce_bucket_bytes'] = [4 * (hi - lo) for lo, hi, _ in allreduce.buckets]
@@ -542,9 +560,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
-    if allreduce is not None:
+    if multi:
         torch.cuda.synchronize()
-        allreduce.close()   # lvae_allreduce_destroy: the private RCCL communicator goes before the process group does
+        step.close()   # lvae_allreduce_destroy: the private RCCL communicator goes before the process group does
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -76,15 +76,19 @@ class GradAllReduce:
     `run()` is the non-overlapped form (everything after backward), kept for LVAE_DDP_MODE=split and for CPU/gloo tensors.
     """
 
-    def __init__(self, flat_grads, group=None, bucket_mb=None, segments=None):
+    def __init__(self, flat_grads, group=None, bucket_mb=None, segments=None, mode=None, comm=None):
         # Which form the exchange takes. On the GPU with a capturable backend (RCCL) the default is 'split': the whole arena as ONE message
         # after backward, between the fwd+bwd graph and the Adamax graph. Measured on MI355X (tools/forced_ab.sh, DESIGN.md §6 round 4): a
         # side branch of a captured graph does not run beside the main branch on this platform — every bucket with real work on it added its
         # full duration (+0.55 ms per 8 MB bucket in the one-rank rehearsal, +4.3 ms for 7 buckets) on top of +0.86 ms for the fork / join
         # edges alone, while the split form costs +0.07 ms. LVAE_DDP_MODE=overlap selects the in-graph overlapped form (completion-ordered
         # buckets on the side stream during backward); eager launches (gloo, CPU) keep it as their default: eager streams do overlap.
+        # Neither default is taken on faith when there is more than one rank: engine.AutoExchangeStep builds BOTH forms (mode= given
+        # explicitly, one shared communicator) and keeps the one that measures faster on the real world size (round 5).
         on_gpu_capturable = flat_grads.is_cuda and dist.is_initialized() and dist.get_backend(group) == 'nccl'
-        self.mode = os.environ.get('LVAE_DDP_MODE', 'split' if on_gpu_capturable else 'overlap')
+        self.mode = mode if mode is not None else os.environ.get('LVAE_DDP_MODE', 'split' if on_gpu_capturable else 'overlap')
+        if self.mode not in ('split', 'overlap'):
+            raise ValueError("gradient exchange form %r: 'split' or 'overlap' ('auto' is engine.AutoExchangeStep's)" % (self.mode,))
         if bucket_mb is None:
             # overlap: 8 MB buckets (xGMI rings are per-link bound; the count was free in round 2's sweep); split: one message
             bucket_mb = float(os.environ.get('LVAE_BUCKET_MB', '8' if self.mode != 'split' else '1048576'))
@@ -113,8 +117,9 @@ class GradAllReduce:
         self.launched = []          # bucket indices in launch order of the current step (tests look at it)
         # Buckets on the GPU go through a communicator of our own (rccl.Comm): its ncclAllReduce is a plain launch on our side stream,
         # with no ProcessGroupNCCL work objects, events or watchdog behind it — which is what makes it safe to capture (rccl.py).
-        self.comm, self.comm_error = None, None
-        if self.on_gpu and self.capturable and (self.world > 1 or self.force):
+        self.comm, self.comm_error = comm, None
+        self.owns_comm = comm is None
+        if comm is None and self.on_gpu and self.capturable and (self.world > 1 or self.force):
             try:
                 from . import rccl
                 self.comm = rccl.Comm(group)
@@ -198,7 +203,8 @@ class GradAllReduce:
     def close(self):
         """Release the private communicator (teardown; the object is unusable for GPU exchanges afterwards)."""
         if self.comm is not None:
-            self.comm.destroy()
+            if self.owns_comm:
+                self.comm.destroy()
             self.comm = None
 
     def _reduce(self, k):
@@ -257,6 +263,47 @@ class GradAllReduce:
         """Reduce all buckets after backward; the caller's current stream waits for completion (no host sync)."""
         self.begin_step()
         self.finish()
+
+
+class FormSelector:
+    """Which of several equivalent forms of a step is fastest HERE (this world size, this fabric): every rank times `trial_steps` steps
+    of each form; a form's cost is the MAX over ranks of its mean step time (the step ends when the slowest rank ends); the decision is
+    taken on those reduced numbers, so every rank takes the same branch. Pure bookkeeping + one small all-reduce: tests/test_dist_cpu.py
+    runs it over gloo with two ranks."""
+
+    def __init__(self, forms, trial_steps=3, group=None, device='cpu'):
+        self.forms = list(forms)
+        self.trial_steps = max(1, int(trial_steps))
+        self.group, self.device = group, device
+        self.samples = {f: [] for f in self.forms}
+        self.timings_ms = None   # {form: ms per step, max over ranks} once decided
+        self.chosen = self.forms[0] if len(self.forms) == 1 else None
+
+    def current(self):
+        """The form whose trial is running (None when all trials are complete)."""
+        for f in self.forms:
+            if len(self.samples[f]) < self.trial_steps:
+                return f
+        return None
+
+    def record(self, form, seconds):
+        self.samples[form].append(float(seconds))
+
+    def complete(self):
+        return self.current() is None
+
+    def decide(self):
+        """Collective: every rank calls it once all its trials are complete. Returns the chosen form."""
+        if self.chosen is not None:
+            return self.chosen
+        mean = torch.tensor([sum(self.samples[f]) / len(self.samples[f]) for f in self.forms], dtype=torch.float64, device=self.device)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            mean = mean.float() if mean.is_cuda else mean   # (RCCL all-reduces fp32 / fp64 alike; keep the gloo path in double)
+            dist.all_reduce(mean, op=dist.ReduceOp.MAX, group=self.group)
+        vals = [float(v) for v in mean.tolist()]
+        self.timings_ms = {f: 1e3 * v for f, v in zip(self.forms, vals)}
+        self.chosen = self.forms[min(range(len(vals)), key=lambda i: (vals[i], i))]   # ties: the first form listed
+        return self.chosen
 
 
 def broadcast_flat(flat, src=0, group=None):

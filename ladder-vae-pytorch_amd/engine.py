@@ -191,3 +191,105 @@ class TrainStep:
             for bn in self._bns:
                 bn._pending += 1
         return self.static_out
+
+
+class AutoExchangeStep:
+    """step(x) for a multi-rank run that does not take the form of its gradient exchange on faith.
+
+    north_star asks for the all-reduce "overlapped with backward on a side HIP stream"; on a one-rank rehearsal that form measured SLOWER
+    inside a captured step than one exposed message between two graphs. Which one wins on N real ranks over xGMI is a
+    measurement this process can make itself: it builds BOTH forms — 'split' (fwd+bwd graph | whole-arena all-reduce | Adamax graph) and
+    'overlap' (completion-ordered 8 MB buckets on the side stream during backward, one graph) — on one shared communicator, runs
+    `trial_steps` timed steps of each after its warm-up / capture steps (all of them REAL training steps: both forms compute the same
+    update), reduces the times with MAX over ranks (dist.FormSelector) and continues with the faster form; the other form's graph is dropped.
+    LVAE_DDP_MODE=split|overlap skips the trial. `timings_ms` / `chosen` go into bench.py's line (config.grad_exchange_ab)."""
+
+    def __init__(self, model, optimizer, flat_grads, segments, group=None, trial_steps=3, forms=None, **step_kwargs):
+        from . import dist as ldist
+        self.model = model
+        env = os.environ.get('LVAE_DDP_MODE')
+        forms = list(forms) if forms is not None else ([env] if env in ('split', 'overlap') else ['split', 'overlap'])
+        self.ars, self.steps = {}, {}
+        comm = None
+        for f in forms:
+            ar = ldist.GradAllReduce(flat_grads, group=group, segments=segments, mode=f, comm=comm)
+            if comm is None:
+                comm = ar.comm
+            st = TrainStep(model, optimizer, allreduce=ar, **step_kwargs)
+            if f == 'overlap' and not st.overlap and 'split' in forms:
+                continue   # the overlapped form is not available here (capture probe refused): it would just be a second 'split'
+            self.ars[f], self.steps[f] = ar, st
+        dev = flat_grads.device
+        self.selector = ldist.FormSelector(list(self.steps), trial_steps, group=group, device=dev if flat_grads.is_cuda else 'cpu')
+        self.group = group
+        self.chosen = self.selector.chosen
+        self.timings_ms = None
+        self._untimed = {}
+        self._arm(self.chosen or self.selector.current())
+
+    def _arm(self, form):
+        st = self.steps[form]
+        self.model.grad_tracker = self.ars[form] if st.overlap else None
+        return st
+
+    @property
+    def ready(self):
+        return self.chosen is not None
+
+    @property
+    def use_graph(self):
+        return self.steps[self.chosen or next(iter(self.steps))].use_graph
+
+    @property
+    def allreduce(self):
+        return self.ars[self.chosen or next(iter(self.ars))]
+
+    def __call__(self, x):
+        if self.chosen is not None:
+            return self.steps[self.chosen](x)
+        import torch.distributed as tdist
+        form = self.selector.current()
+        st = self._arm(form)
+        # eager warm-up steps and the capturing step are not timed; without a graph, the first step of a form (lazy initialisations) is not
+        warming = (st.use_graph and (st.eager_left > 0 or st.graph_a is None)) or self._untimed.get(form, 0) < 1
+        if warming:
+            self._untimed[form] = self._untimed.get(form, 0) + 1
+            return st(x)
+        on_gpu = x.is_cuda
+        if tdist.is_initialized() and tdist.get_world_size(self.group) > 1:
+            tdist.barrier(group=self.group)
+        if on_gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = st(x)
+        if on_gpu:
+            torch.cuda.synchronize()
+        self.selector.record(form, time.perf_counter() - t0)
+        if self.selector.complete():
+            self.chosen = self.selector.decide()
+            self.timings_ms = self.selector.timings_ms
+            for f in list(self.steps):
+                if f != self.chosen:   # the loser's graphs (and their memory pools) go
+                    self.steps[f].graph_a = self.steps[f].graph_b = None
+                    self.steps[f].static_out = None
+            self._arm(self.chosen)
+            print('[lvae] gradient exchange: %s' % self.exchange_description(), file=sys.stderr, flush=True)
+        return out
+
+    def exchange_description(self):
+        if self.chosen is None:
+            return 'undecided (trial steps still running)'
+        d = self.steps[self.chosen].exchange_description()
+        if self.timings_ms:
+            d += ' | chosen at run time: ' + ', '.join('%s %.3f ms/step' % (f, t) for f, t in self.timings_ms.items()) + \
+                 ' (max over ranks of %d timed steps each)' % self.selector.trial_steps
+        return d
+
+    def close(self):
+        seen = set()
+        for ar in self.ars.values():
+            if ar.comm is not None and id(ar.comm) not in seen and ar.owns_comm:
+                seen.add(id(ar.comm))
+                ar.close()
+            else:
+                ar.comm = None

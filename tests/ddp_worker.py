@@ -76,6 +76,32 @@ def main():
         dump(out, m, {'losses': losses, 'buckets': ar.buckets, 'launched': ar.launched})
         ar.close()
         torch.distributed.destroy_process_group()
+    elif mode == 'rccl1_auto':
+        # what a multi-rank bench / training run does (round 5): both exchange forms are built on one communicator, a few trial steps of
+        # each are timed, the faster one is kept; every trial step is a real training step
+        os.environ['LVAE_FORCE_DIST'] = '1'
+        os.environ.pop('LVAE_DDP_MODE', None)
+        from lvae_amd.engine import AutoExchangeStep
+        rank, world, _ = ldist.init_from_env('nccl')
+        m, opt = build(0)
+        arena = m.pack()
+        ldist.broadcast_flat(arena.params)
+        step = AutoExchangeStep(m, opt, arena.grads, arena.segments, trial_steps=2, use_graph=True)
+        assert sorted(step.steps) == ['overlap', 'split'] and step.ars['split'].comm is step.ars['overlap'].comm is not None
+        assert len(step.ars['split'].buckets) == 1 and len(step.ars['overlap'].buckets) >= 1
+        losses, forms = [], []
+        for x in batches(steps, 1):
+            forms.append(step.chosen or step.selector.current())
+            losses.append(float(step(x.cuda())['loss']))
+        torch.cuda.synchronize()
+        assert step.ready and step.chosen in ('split', 'overlap') and set(step.timings_ms) == {'split', 'overlap'}
+        assert all(t > 0 for t in step.timings_ms.values()) and 'chosen at run time' in step.exchange_description()
+        loser = 'overlap' if step.chosen == 'split' else 'split'
+        assert step.steps[loser].graph_a is None and step.steps[step.chosen].graph_a is not None
+        assert (m.grad_tracker is step.ars['overlap']) == (step.chosen == 'overlap')
+        dump(out, m, {'losses': losses, 'forms': forms, 'chosen': step.chosen, 'timings_ms': step.timings_ms})
+        step.close()
+        torch.distributed.destroy_process_group()
     elif mode == 'rccl1':
         os.environ['LVAE_FORCE_DIST'] = '1'
         os.environ['LVAE_DDP_MODE'] = 'overlap'

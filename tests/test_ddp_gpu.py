@@ -136,6 +136,24 @@ def test_forced_rccl_rank_default_split_exchange_matches_single_rank(tmp_path):
     assert rb['extra']['launched'] == [0]
 
 
+def test_exchange_form_chosen_at_run_time_on_a_forced_rank_matches_single_rank(tmp_path):
+    """engine.AutoExchangeStep on one forced RCCL rank: 2 x (2 eager + capture + 2 timed) trial steps, then the faster
+    form; since every trial step is a real training step, parameters / BatchNorm statistics / losses after 14 steps equal the plain
+    single-rank run's, whichever form was running at which step."""
+    a, b = str(tmp_path / 'single.pt'), str(tmp_path / 'auto.pt')
+    _run('single', a, 14)
+    _run('rccl1_auto', b, 14)
+    ra, rb = torch.load(a), torch.load(b)
+    la, lb = ra['extra']['losses'], rb['extra']['losses']
+    assert max(abs(u - v) / abs(u) for u, v in zip(la, lb)) < 1e-6, (la, lb)
+    assert _max_rel(rb['sd'], ra['sd']) < 1e-6
+    forms = rb['extra']['forms']
+    assert forms[:5] == ['split'] * 5 and forms[5:10] == ['overlap'] * 5 and set(forms[10:]) == {rb['extra']['chosen']}, forms
+    for k in ra['sd']:
+        if k.endswith('num_batches_tracked'):
+            assert int(ra['sd'][k]) == int(rb['sd'][k]) == 14, k
+
+
 def test_capture_refusing_collective_falls_back_to_split_in_process(tmp_path):
     """if the gradient exchange cannot be captured (GradAllReduce.capture_probe meets a refusal), the SAME process
     continues with the exchange outside the step graph; parameters, BatchNorm statistics (incl. num_batches_tracked) and losses equal

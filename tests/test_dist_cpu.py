@@ -81,6 +81,54 @@ def test_world_size_2_gloo_allreduce_and_sharding():
         assert r[8] == [30.0, -9.0, 9.0]
 
 
+def _selector_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import lvae_amd  # noqa: F401
+    from lvae_amd import dist as ldist
+    ldist.init_from_env('gloo')
+    # rank 0 sees 'overlap' faster, rank 1 sees it MUCH slower (e.g. its side branch is serialised): the step ends when the slowest rank
+    # ends, so the cost of a form is the max over ranks, and both ranks must take the same branch
+    times = {0: {'split': [0.030, 0.031, 0.029], 'overlap': [0.028, 0.028, 0.027]},
+             1: {'split': [0.031, 0.031, 0.030], 'overlap': [0.034, 0.035, 0.034]}}[rank]
+    sel = ldist.FormSelector(['split', 'overlap'], trial_steps=3)
+    order = []
+    while not sel.complete():
+        f = sel.current()
+        order.append(f)
+        sel.record(f, times[f][len(sel.samples[f])])
+    chosen = sel.decide()
+    # a tie (identical numbers on both forms) goes to the first form listed, on every rank
+    tie = ldist.FormSelector(['split', 'overlap'], trial_steps=1)
+    tie.record('split', 0.01)
+    tie.record('overlap', 0.01)
+    q.put((rank, order, chosen, sel.timings_ms, tie.decide(), ldist.FormSelector(['overlap']).chosen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_form_selection_takes_the_max_over_ranks_and_one_branch_everywhere():
+    """dist.FormSelector (engine.AutoExchangeStep's decision) over gloo with two ranks whose timings disagree."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_selector_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] == ['split'] * 3 + ['overlap'] * 3            # trials run form by form, in the listed order, on every rank
+        assert r[2] == 'split'                                    # max over ranks: split 30.7 ms, overlap 34.3 ms
+        assert abs(r[3]['split'] - 30.667) < 0.01 and abs(r[3]['overlap'] - 34.333) < 0.01, r[3]
+        assert r[4] == 'split' and r[5] == 'overlap'              # tie -> first form; a single form needs no trial
+    assert res[0][3] == res[1][3]
+
+
 def test_bucket_slices_cover_exactly():
     import lvae_amd  # noqa: F401
     from lvae_amd.dist import bucket_slices, shard_batch
