@@ -51,12 +51,8 @@ static_assert(sizeof(WgImgGroup) <= 4096, "kernel argument block");
 constexpr int WGI_LDK = 72;    // bf16 elements per x row (64 channels + 8 pad = 144 bytes)
 constexpr int WGI_LDD1 = 136;  // bf16 elements per dy row of the 1x1 kind (128 channels + 8 pad)
 
-// XV: 32-pixel passes over the patch (halo_px <= 32 XV).
-// DB: two sets of planes (where 160 KB of LDS hold them: the 8x8 level and the 1x1 kind). The staging of tile i + 1 and the MFMAs of tile i
-// then share an iteration with ONE barrier, and the two waves of a SIMD (waves w and w + 4) take the two halves in opposite order, so that
-// one wave's staging (vector ALU, LDS writes) runs beside the other's MFMAs instead of all eight waves marching through stage | barrier |
-// MFMA | barrier together (measured in the step, 8x8 level: 7.2 us per tile in that form against 2.9 us of MFMAs).
-template <int KIND, int SPLIT, int XV, bool DB>
+// XV: 32-pixel passes over the patch (halo_px <= 32 XV)
+template <int KIND, int SPLIT, int XV>
 __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
   constexpr int LDK = WGI_LDK, LDD = KIND == 0 ? WGI_LDK : WGI_LDD1;
   constexpr int NTAP = KIND == 0 ? 9 : 1, NACC = KIND == 0 ? 5 : 1;
@@ -67,10 +63,10 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
   const WgImgProb& a = g.p[blockIdx.y];
   if ((int)blockIdx.x >= a.nwg) return;   // uniform per workgroup, before any barrier
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* Xs0 = reinterpret_cast<__bf16*>(smem_raw);   // per buffer: [SPLIT][halo_px][LDK] x planes, then [SPLIT][64][LDD] dy planes
+  __bf16* Xs = reinterpret_cast<__bf16*>(smem_raw);   // [SPLIT][halo_px][LDK]
   const int x_plane = a.halo_px * LDK;
+  __bf16* Ds = Xs + (size_t)SPLIT * x_plane;          // [SPLIT][64][LDD]
   constexpr int d_plane = 64 * LDD;
-  const int buf_elems = SPLIT * (x_plane + d_plane);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cih = wave & 1;
   const int cob = KIND == 0 ? ((wave >> 1) & 1) : (wave >> 1);   // 32-channel block of the output channels
@@ -92,7 +88,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
   const int chd = cob * 32 + 16 * (G & 1) + 4 * (i16 & 3);   // ... in a dy row
   const int drow0 = 8 * (G >> 1) + (i16 >> 2);
 
-  // staging maps: thread -> (pixel, 4 channels); the raw operands of a later tile live in registers during the MFMAs
+  // staging maps: thread -> (pixel, 4 channels); the raw operands of the next tile live in registers during the MFMAs
   const int c4 = (t & 15) * 4, px0 = t >> 4;
   const int c4d = (t & (DCH - 1)) * 4, pxd0 = t / DCH;
   const bool cx_ok = c4 < Cin, cd_ok = c4d < Cout;
@@ -137,10 +133,10 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   f32x4 bsum = zero4;
 
-  // registers -> LDS planes of buffer `buf` (transform, exact split / rounding to bf16); rows that do not exist are zero
-  auto stage = [&](int buf) {
-    __bf16* Xs = Xs0 + (size_t)buf * buf_elems;
-    __bf16* Ds = Xs + (size_t)SPLIT * x_plane;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) prefetch(tile);
+  for (; tile < a.ntiles; tile += a.nwg) {
+    // registers -> LDS planes (transform, exact split / rounding to bf16); rows that do not exist are zero
 #pragma unroll
     for (int u = 0; u < XV; ++u) {
       const int px = px0 + 32 * u;
@@ -166,13 +162,11 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
 #pragma unroll
       for (int q = 0; q < SPLIT; ++q) *reinterpret_cast<bf16x4*>(Ds + q * d_plane + p * LDD + c4d) = pl[q];
     }
-  };
-  // the tile in buffer `buf`: 4 k-steps of 16 pixels
-  auto mma = [&](int buf) {
-    const __bf16* Xs = Xs0 + (size_t)buf * buf_elems;
-    const __bf16* Ds = Xs + (size_t)SPLIT * x_plane;
+    __syncthreads();
+    if (tile + a.nwg < a.ntiles) prefetch(tile + a.nwg);
+
 #pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4; ++s) {   // k-steps of 16 pixels
       const int xr0 = xrow_of(s, 0), xr1 = xrow_of(s, 1);
       bf16x8 bfr[SPLIT];
 #pragma unroll
@@ -199,43 +193,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
         }
       }
     }
-  };
-
-  int tile = blockIdx.x;
-  if (tile < a.ntiles) prefetch(tile);
-  if (DB) {
-    if (tile < a.ntiles) {
-      stage(0);
-      if (tile + a.nwg < a.ntiles) prefetch(tile + a.nwg);
-    }
-    lds_barrier();   // (LDS only: the global loads just requested stay in flight)
-    const bool stage_first = (wave & 4) != 0;
-    for (int it = 0; tile < a.ntiles; tile += a.nwg, ++it) {
-      const int cur = it & 1;
-      const bool has_next = tile + a.nwg < a.ntiles;
-      if (stage_first) {
-        if (has_next) {
-          stage(cur ^ 1);
-          if (tile + 2 * a.nwg < a.ntiles) prefetch(tile + 2 * a.nwg);
-        }
-        mma(cur);
-      } else {
-        mma(cur);
-        if (has_next) {
-          stage(cur ^ 1);
-          if (tile + 2 * a.nwg < a.ntiles) prefetch(tile + 2 * a.nwg);
-        }
-      }
-      lds_barrier();   // buffer cur is read, buffer cur ^ 1 is published
-    }
-  } else {
-    for (; tile < a.ntiles; tile += a.nwg) {
-      stage(0);
-      __syncthreads();
-      if (tile + a.nwg < a.ntiles) prefetch(tile + a.nwg);
-      mma(0);
-      __syncthreads();  // the planes are read: the next tile overwrites them
-    }
+    __syncthreads();  // the planes are read: the next tile overwrites them
   }
 
   // partial slab straight from the accumulators (row = ci, 32 consecutive co per lane half)
@@ -252,7 +210,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
     }
   }
   if (a.slab_b) {
-    float* red = reinterpret_cast<float*>(smem_raw);   // [DPX pixel groups][4 DCH] (the planes are dead: the loop ended with a barrier)
+    float* red = reinterpret_cast<float*>(smem_raw);   // [DPX pixel groups][4 DCH]
     *reinterpret_cast<f32x4*>(red + pxd0 * (4 * DCH) + c4d) = bsum;
     __syncthreads();
     if (t < 4 * DCH) {
@@ -332,9 +290,9 @@ struct ReduceArgs {
 };
 void wgrad_reduce_grouped_launch(const ReduceArgs* r, int n, hipStream_t s);
 
-template <int KIND, int SPLIT, int XV, bool DB>
-static int wgi_launch2(const WgImgGroup& g, int n, int max_wgs, size_t lds, hipStream_t s) {
-  auto kern = wgrad_img_kernel<KIND, SPLIT, XV, DB>;
+template <int KIND, int SPLIT, int XV>
+static int wgi_launch(const WgImgGroup& g, int n, int max_wgs, size_t lds, hipStream_t s) {
+  auto kern = wgrad_img_kernel<KIND, SPLIT, XV>;
   static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -347,17 +305,6 @@ static int wgi_launch2(const WgImgGroup& g, int n, int max_wgs, size_t lds, hipS
   hipLaunchKernelGGL(kern, dim3(max_wgs, n), dim3(512), lds, s, g);
   LVAE_LAUNCH_CHECK("conv_wgrad_img");
   return 0;
-}
-
-#ifndef LVAE_WGRAD_IMG_DB
-#define LVAE_WGRAD_IMG_DB 1
-#endif
-// two sets of planes when they fit (lds = bytes of one set)
-template <int KIND, int SPLIT, int XV>
-static int wgi_launch(const WgImgGroup& g, int n, int max_wgs, size_t lds, hipStream_t s) {
-  static const bool db_on = tune("LVAE_WGRAD_IMG_DB", LVAE_WGRAD_IMG_DB) != 0;   // A/B switch (tuning builds only)
-  if (db_on && 2 * lds <= 160 * 1024) return wgi_launch2<KIND, SPLIT, XV, true>(g, n, max_wgs, 2 * lds, s);
-  return wgi_launch2<KIND, SPLIT, XV, false>(g, n, max_wgs, lds, s);
 }
 
 template <int KIND, int SPLIT>
