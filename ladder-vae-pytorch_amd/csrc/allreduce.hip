@@ -11,6 +11,9 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+#include <string>
+
 #include "lvae_common.h"
 
 namespace lvae {
@@ -44,10 +47,25 @@ struct AllReduceHandle {
   int world = 0, rank = 0;
 };
 
+// One handle per process: the library the caller names is first looked up among the objects ALREADY mapped (RTLD_NOLOAD — in a
+// torch process that is the librccl ProcessGroupNCCL uses, so no second copy of RCCL is injected); only if it is not mapped yet is it
+// loaded, with local symbol visibility. The handle is cached (and intentionally never closed: the communicators outlive any call).
 static int rccl_open(const char* path, RcclApi& a) {
   LVAE_REQUIRE(path != nullptr, LVAE_EINVAL, "lvae_allreduce: null librccl path");
-  a.lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-  LVAE_REQUIRE(a.lib != nullptr, LVAE_EINVAL, "lvae_allreduce: dlopen(%s) failed: %s", path, dlerror());
+  static std::mutex mu;
+  static void* cached = nullptr;
+  static std::string cached_path;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached == nullptr || cached_path != path) {
+      void* h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
+      if (h == nullptr) h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+      LVAE_REQUIRE(h != nullptr, LVAE_EINVAL, "lvae_allreduce: dlopen(%s) failed: %s", path, dlerror());
+      cached = h;
+      cached_path = path;
+    }
+    a.lib = cached;
+  }
   a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
   a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));

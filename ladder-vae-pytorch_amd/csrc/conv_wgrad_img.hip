@@ -60,6 +60,11 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
   constexpr int DV = KIND == 0 ? 2 : 4;           // float4 of the dy tile per thread
   constexpr int DCH = KIND == 0 ? 16 : 32;        // float4 per dy row
   constexpr int DPX = 512 / DCH;                  // dy pixel rows per pass
+#ifdef LVAE_WGI_DBG  // compile-time phase-skip mask of the profiling builds (tools/wgi_ab.sh); never defined in the product
+  constexpr int dbg = LVAE_WGI_DBG;  // 1: no global loads, 2: no MFMAs, 4: no staging arithmetic / LDS writes, 8: fragments not read from LDS, 16: no slab stores
+#else
+  constexpr int dbg = 0;
+#endif
   const WgImgProb& a = g.p[blockIdx.y];
   if ((int)blockIdx.x >= a.nwg) return;   // uniform per workgroup, before any barrier
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
       const int n = n0 + img, ih = hy - PAD, iw = hx - PAD;
       const bool ok = (px < a.halo_px) & (n < a.N) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)a.W) & cx_ok;
       const size_t off = ok ? ((size_t)n * HW + ih * a.W + iw) * Cin + c4 : 0;
-      xr[u] = *reinterpret_cast<const f32x4*>(a.x + off);
+      xr[u] = (dbg & 1) ? zero4 : *reinterpret_cast<const f32x4*>(a.x + off);
       xok |= ok ? (1u << u) : 0u;
     }
     dok = 0;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
       const int img = fastdiv(p, a.m_hw);
       const bool ok = (n0 + img < a.N) & cd_ok;
       const size_t off = ok ? ((size_t)n0 * HW + p) * Cout + c4d : 0;
-      dr[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
+      dr[u] = (dbg & 1) ? zero4 : *reinterpret_cast<const f32x4*>(a.dy + off);
       dok |= ok ? (1u << u) : 0u;
     }
   };
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
   if (tile < a.ntiles) prefetch(tile);
   for (; tile < a.ntiles; tile += a.nwg) {
     // registers -> LDS planes (transform, exact split / rounding to bf16); rows that do not exist are zero
+    if (!(dbg & 4))
 #pragma unroll
     for (int u = 0; u < XV; ++u) {
       const int px = px0 + 32 * u;
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
         for (int q = 0; q < SPLIT; ++q) *reinterpret_cast<bf16x4*>(Xs + q * x_plane + px * LDK + c4) = pl[q];
       }
     }
+    if (!(dbg & 4))
 #pragma unroll
     for (int u = 0; u < DV; ++u) {
       const int p = pxd0 + DPX * u;
@@ -171,7 +178,8 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
       bf16x8 bfr[SPLIT];
 #pragma unroll
       for (int q = 0; q < SPLIT; ++q)
-        bfr[q] = tr_frag(Ds + q * d_plane + (16 * s + drow0) * LDD + chd, Ds + q * d_plane + (16 * s + drow0 + 4) * LDD + chd);
+        bfr[q] = (dbg & 8) ? __builtin_bit_cast(bf16x8, f32x4{(float)s, (float)q, 1.f, 2.f})
+                           : tr_frag(Ds + q * d_plane + (16 * s + drow0) * LDD + chd, Ds + q * d_plane + (16 * s + drow0 + 4) * LDD + chd);
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         if (j < ntap) {
@@ -179,7 +187,13 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
           const int off = KIND == 0 ? kh * a.halo_w + kw : 0;
           bf16x8 afr[SPLIT];
 #pragma unroll
-          for (int q = 0; q < SPLIT; ++q) afr[q] = tr_frag(Xs + q * x_plane + (xr0 + off) * LDK + chx, Xs + q * x_plane + (xr1 + off) * LDK + chx);
+          for (int q = 0; q < SPLIT; ++q)
+            afr[q] = (dbg & 8) ? __builtin_bit_cast(bf16x8, f32x4{(float)(xr0 + off), (float)q, (float)xr1, 2.f})
+                               : tr_frag(Xs + q * x_plane + (xr0 + off) * LDK + chx, Xs + q * x_plane + (xr1 + off) * LDK + chx);
+          if (dbg & 2) {
+#pragma unroll
+            for (int q = 0; q < SPLIT; ++q) asm volatile("" ::"v"(afr[q]), "v"(bfr[q]));
+          } else
           if (SPLIT == 1) {
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], acc[j], 0, 0, 0);
           } else {  // piece products in ascending order of magnitude
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(512) void wgrad_img_kernel(WgImgGroup g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = cob * 32 + li;
-        if (ci < Cin && co < Cout) sw[((size_t)tap * Cin + ci) * Cout + co] = acc[j][r];
+        if (ci < Cin && co < Cout && !((dbg & 16) && acc[j][r] != 12345.f)) sw[((size_t)tap * Cin + ci) * Cout + co] = acc[j][r];
       }
     }
   }

@@ -128,21 +128,30 @@ class TrainStep:
         # thread_local: the RCCL watchdog thread of an initialised process group may query events while this thread captures.
         # (Whether the exchange CAN be captured was settled by GradAllReduce.capture_probe() in __init__: a refusal inside this capture
         # would leave a half-captured training step behind, and unwinding that is not safe.)
+        # Host-side counters the Python pass advances while it is captured: if EITHER capture fails they go back, so that a caller who catches
+        # the error and steps again neither replays half a step (graph A without the exchange and the optimizer) nor counts a BatchNorm
+        # forward / a global step that never ran
+        bns = self.model.bn_modules()
+        pend0 = [bn._pending for bn in bns]
         try:
             with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
                 self.static_out = self._fwd_bwd(self.static_x)
                 if fused:
                     self.opt.step()
+            if not fused:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
+                    self.opt.step()
         except BaseException:
-            # a failed capture leaves no usable graph: drop it so that the next call captures again (or runs eagerly) from clean state
+            # a failed capture leaves no usable graph: drop both so that the next call captures again (or runs eagerly) from clean state
             self.graph_a = self.graph_b = None
             self.static_out = None
+            self._table_ref = None
+            for bn, p0 in zip(bns, pend0):
+                bn._pending = p0
+            self.model.global_step -= 1   # __call__ counted this step before capturing it
             raise
-        if not fused:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode='thread_local'):
-                self.opt.step()
-        self._bns = self.model.bn_modules()
+        self._bns = bns
         # the captured prepare_all launch baked in the device address (and entry count) of the transformed-weight table: keep exactly
         # that table, and the scratch buffers its entries point to, alive and unmodified for as long as this graph can be replayed
         self._table_ref = K.prepared.pin_current()

@@ -169,6 +169,7 @@ class _PreparedWeights:
             self.entries[key] = ent
             self.table = None
         d.workspace, d.workspace_bytes = ent['U'].data_ptr(), ent['U'].numel()
+        d._ws_tensor = ent['U']   # (a Python attribute of the ctypes object: lets a caller keep the scratch buffer alive, rb_weight_ranges)
         d.workspace_ready = 1 if (self.enabled and ent['stamp'] == self.stamp(weight)) else 0
 
     def prepare_all(self):
@@ -449,6 +450,7 @@ def _rb_gate_ws(e, gate_w, gate_g, device, bwd):
     prepared.attach(gd, gate_w, device, need, 'lvae_resblock_gate_prepare_entry')
     e.gate_w, e.gate_w_sk, e.gate_w_sn = gd.w, gd.w_sk, gd.w_sn
     e.gate_ws, e.gate_ws_bytes, e.gate_ws_ready = gd.workspace, gd.workspace_bytes, gd.workspace_ready
+    e._ws_tensor = gd._ws_tensor
 
 
 def rb_rows(x, weight, g):
@@ -497,20 +499,23 @@ def _rb_in_bn(d, in_bn, x, can_fold=True):
 
 
 def rb_weight_ranges(x_like, weight, g, dgrad, gate=None, gate_bwd=False):
-    """[(device pointer, bytes)] of the pre-split weights a later fused launch will stream: the 3x3 convolution (weight, g) in the given
-    direction and optionally the gate (gate = (gate_w, gate_g)). For the `prefetch` argument of the launch that runs just before it."""
+    """[(device pointer, bytes, buffer)] of the pre-split weights a later fused launch will stream: the 3x3 convolution (weight, g) in the
+    given direction and optionally the gate (gate = (gate_w, gate_g)). For the `prefetch` argument of the launch that runs just before it.
+    The third element is the scratch tensor itself: whoever remembers a range (ops' cross-block links, baked into captured graphs as raw
+    addresses) thereby keeps the memory allocated, whatever happens to the transformed-weight cache in between (evict_dead, a cleared
+    cache, a precision switch) — a stale range is then touched uselessly, never a freed one."""
     d, need = _rb_desc(x_like, weight, g, dgrad)
-    out = [(int(d.workspace), int(need))] if need else []
+    out = [(int(d.workspace), int(need), d._ws_tensor)] if need else []
     if gate is not None:
         e = RbExt()
         _rb_gate_ws(e, gate[0], gate[1], x_like.device, gate_bwd)
-        out.append((int(e.gate_ws), int(e.gate_ws_bytes)))
+        out.append((int(e.gate_ws), int(e.gate_ws_bytes), e._ws_tensor))
     return out
 
 
 def _rb_prefetch(e, prefetch):
-    for i, (p, n) in enumerate((prefetch or [])[:2]):
-        e.pf_ptr[i], e.pf_bytes[i] = p, n
+    for i, rng in enumerate((prefetch or [])[:2]):
+        e.pf_ptr[i], e.pf_bytes[i] = rng[0], rng[1]
 
 
 def rb_conv(x, weight, g, bias, in_act, out_scale, in_bn=None, coef=None, stats_pivot=None, prefetch=None):

@@ -158,7 +158,8 @@ _GATE_STATS = os.environ.get('LVAE_NO_GATE_STATS') is None  # A/B switch, profil
 # The fused blocks of the low-resolution levels run as one dependent chain, and every launch streams weights of its own that are cold in
 # the L2s. Inside a block the first launch warms the L2s for the second (kernels.rb_weight_ranges); ACROSS blocks the order is only known
 # from the previous step: each block remembers which fused block ran right after it (per direction) and what that block's first launch
-# streams. Speed only: a stale link makes a launch touch bytes nobody needs (the buffers stay alive as long as their weights do).
+# streams. Speed only: a stale link makes a launch touch bytes nobody needs; the link holds the scratch tensors themselves (third element of a
+# range, kernels.rb_weight_ranges), so the addresses a launch — or a captured graph — touches stay allocated whatever the cache does.
 import weakref as _weakref
 
 _rb_chain = {'fwd': None, 'bwd': None}

@@ -80,3 +80,15 @@ class Comm:
         if self.handle:
             _C.load().lvae_allreduce_destroy(self.handle)
             self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __del__(self):   # a communicator nobody closed must not leak its RCCL comm and two events
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may be gone already)
+            pass

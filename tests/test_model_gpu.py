@@ -189,12 +189,16 @@ def test_exception_inside_a_captured_backward_leaves_a_clean_state(monkeypatch):
     torch.cuda.synchronize()
     assert s1.graph_a is None and not ops._side.get('group_q')
     assert all(e['stamp'] is None for e in K.prepared.entries.values())
-    m1.global_step -= 1            # the failed call counted a step that did not happen
+    assert m1.global_step == 2     # the failed call's step count and BatchNorm forward counts were taken back
     for x in xs[2:]:
         s1(x)                      # captures again, then replays
     torch.cuda.synchronize()
     assert s1.graph_a is not None
     assert float((m1.arena.params - ref).abs().max()) < 1e-6
+    assert m1.global_step == m0.global_step == 5
+    sd0, sd1 = m0.state_dict(), m1.state_dict()
+    nbt = [k for k in sd0 if k.endswith('num_batches_tracked')]
+    assert nbt and all(int(sd0[k]) == int(sd1[k]) == 5 for k in nbt)
 
 
 def test_cfg1_mnist3_batch64_matches_reference():
