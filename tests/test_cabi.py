@@ -53,6 +53,30 @@ def test_struct_layout_matches_header():
     assert names == [f[0] for f in ConvDesc._fields_]
 
 
+def _header_fields(struct):
+    hdr = open(os.path.join(ROOT, 'include', 'lvae_hip.h')).read()
+    body = hdr[hdr.index('typedef struct %s {' % struct):hdr.index('} %s;' % struct)]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    body = body[body.index('{') + 1:]
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for ty in ('const float*', 'const void*', 'float*', 'void*', 'int32_t', 'int64_t', 'uint8_t', 'float '):
+            decl = decl.replace(ty, '')
+        names += [re.sub(r'\[\d+\]', '', n).strip() for n in decl.split(',') if n.strip()]
+    return names
+
+
+@pytest.mark.parametrize('struct,cls', [('lvae_rb_ext', 'RbExt'), ('lvae_bn_apply', 'BnApply'), ('lvae_bn_fold', 'BnFold')])
+def test_extension_struct_layouts_match_header(struct, cls):
+    """the structs that carry the fused launches' extras (round 5 added the deferred BatchNorm-backward apply to both)"""
+    import lvae_amd  # noqa: F401
+    from lvae_amd import _C
+    assert _header_fields(struct) == [f[0] for f in getattr(_C, cls)._fields_]
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     import lvae_amd  # noqa: F401
