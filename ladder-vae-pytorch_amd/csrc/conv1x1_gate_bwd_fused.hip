@@ -197,7 +197,11 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_kernel(GbfArgs a) 
 // them with the transposing ds_read_b64_tr_b16 (bf16_frag.h), as conv3x3_wgrad_bf16_kernel does.
 constexpr int GBB_LDA = 136;  // dab row pitch in bf16 (128 channels + 8: 272 bytes, 16-byte multiples for ds_read_b128)
 constexpr int GBB_LDY = 72;   // y row pitch in bf16
-constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4 + 6 * 64 * 4; }
+// + the deferred apply's coefficient rows [6][64] and, in the six-product form, the dgrad's pre-split W fragments [8 k-steps][2 column halves][3][64 lanes][8]
+// (48 KB: in registers they were 96 VGPRs of every wave of a kernel at the 256-register cap; with the deferred apply's extra operand rows it spilled)
+constexpr size_t gbb_lds(int split) {
+  return (size_t)split * (64 * GBB_LDA + 64 * GBB_LDY) * 2 + (size_t)64 * GB_LDY * 4 + 6 * 64 * 4 + (split == 3 ? (size_t)8 * 2 * 3 * 64 * 16 : 0);
+}
 
 // S16 (SPLIT == 1): ab, y and dx are bf16-stored (residual-block internals under compute_dtype bf16) and move as 16-byte pieces: a thread
 // takes 8 channels of ONE pixel row per tile (5 loads of 16 bytes instead of 8, one 16-byte store instead of two of 8).
@@ -205,9 +209,13 @@ constexpr size_t gbb_lds(int split) { return (size_t)split * (64 * GBB_LDA + 64 
 // just before (its input is this block's output): dout = BN'(ap.dh; ap.x) + ap.add. The persistent workgroups reduce the producer's
 // partial rows once (fixed order), then form dout while they stage a tile and store it to ap.out (this block's own last apply reads it as
 // its `add`); workgroup 0 accumulates dgamma / dbeta. Saves the apply launch, its finalize launch and one 16.8 MB pass per gated block.
-template <int SPLIT, bool S16 = false, bool AP = false>
+// ELU: both activation ids of the launch are LVAE_ACT_ELU (the model's default), known at compile time. With run-time ids every one of the
+// staging loop's 16 per-element activation calls is a chain of scalar compares and taken branches (the emitted staging segment of the
+// round-4 kernel held ~300 branch instructions; resblock_img.hip found the same in round 4).
+template <int SPLIT, bool S16 = false, bool AP = false, bool ELU = false>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
   kernarg_warmup<sizeof(GbfArgs)>();
+  const int gact = ELU ? LVAE_ACT_ELU : a.act, apact = ELU ? LVAE_ACT_ELU : a.ap.act;
   static_assert(SPLIT == 1 || !S16, "bf16 storage exists for the bf16-operand form only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int A_PLANE = 64 * GBB_LDA, Y_PLANE = 64 * GBB_LDY;
@@ -262,13 +270,16 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
     const f32x4 u = xv * sc + sh;
     f32x4 g;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = dh[j] * act_grad(u[j], a.ap.act);
+    for (int j = 0; j < 4; ++j) g[j] = dh[j] * act_grad(u[j], apact);
     return (g - c1 - (xv - mu) * rs * c2) * sc + ad;
   };
 
-  // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s, SPLIT pieces
-  bf16x8 breg[8][SPLIT];
-  if (!wg_role) {
+  // dgrad waves: W[co = 16 s + 8 lh + 0..7][ci = wn*32 + li] as the B fragment of k-step s, SPLIT pieces: in registers (bf16 operands) or,
+  // in the six-product form, in LDS in fragment order (written once by waves 0 / 1, published by the first barrier below)
+  constexpr bool WLDS = SPLIT == 3;
+  bf16x8* Wf = reinterpret_cast<bf16x8*>(Cf + 6 * 64);   // [8][2][SPLIT][64]
+  bf16x8 breg[WLDS ? 1 : 8][SPLIT];
+  if (!wg_role && (!WLDS || wm == 0)) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const float* wp = a.w + (int64_t)(wn * 32 + li) * a.w_sn + 16 * s + 8 * lh;
@@ -276,8 +287,11 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       split4<SPLIT>(*reinterpret_cast<const f32x4*>(wp), lo);
       split4<SPLIT>(*reinterpret_cast<const f32x4*>(wp + 4), hi);
 #pragma unroll
-      for (int q = 0; q < SPLIT; ++q)
-        breg[s][q] = bf16x8{lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
+      for (int q = 0; q < SPLIT; ++q) {
+        const bf16x8 v = bf16x8{lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
+        if (WLDS) Wf[((s * 2 + wn) * SPLIT + q) * 64 + lane] = v;
+        else breg[s][q] = v;
+      }
     }
   }
 
@@ -360,8 +374,8 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
           for (int j = 0; j < 4; ++j) {
             const float av = (float)qa[4 * h + j], bv = (float)qb[4 * h + j];
             const float sg = sigmoidf_(bv);
-            lo[h][j] = pg[h][j] * sg * act_grad(av, a.act);
-            hi[h][j] = pg[h][j] * act_fwd(av, a.act) * sg * (1.f - sg);
+            lo[h][j] = pg[h][j] * sg * act_grad(av, gact);
+            hi[h][j] = pg[h][j] * act_fwd(av, gact) * sg * (1.f - sg);
           }
         yv = qy;
       }
@@ -385,8 +399,8 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float sg = sigmoidf_(pb[u][j]);
-          lo[j] = pg[u][j] * sg * act_grad(pa[u][j], a.act);
-          hi[j] = pg[u][j] * act_fwd(pa[u][j], a.act) * sg * (1.f - sg);
+          lo[j] = pg[u][j] * sg * act_grad(pa[u][j], gact);
+          hi[j] = pg[u][j] * act_fwd(pa[u][j], gact) * sg * (1.f - sg);
         }
         yv = py[u];
       }
@@ -417,8 +431,16 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
 #pragma unroll
         for (int q = 0; q < SPLIT; ++q)
           af[q] = *reinterpret_cast<const bf16x8*>(As + q * A_PLANE + (wm * 32 + li) * GBB_LDA + 16 * s + 8 * lh);
+        if (WLDS) {
+          bf16x8 bw[SPLIT];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], breg[s][PB[k]], accx, 0, 0, 0);
+          for (int q = 0; q < SPLIT; ++q) bw[q] = Wf[((s * 2 + wn) * SPLIT + q) * 64 + lane];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bw[PB[k]], accx, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], breg[s][PB[k]], accx, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GB_LDY + wn * 32 + li] = accx[r];
@@ -572,28 +594,34 @@ int conv1x1_gate_bwd_fused(const lvae_conv_desc* d, const float* dout, const flo
     set_error("conv1x1_gate_bwd_fused: the deferred BatchNorm-backward apply exists in the bf16-matrix-pipe kernels only (not with LVAE_FORM_F32_MFMA)");
     return LVAE_EINVAL;
   }
+  const bool elu = act == LVAE_ACT_ELU && (!with_ap || a.ap.act == LVAE_ACT_ELU);
+#define GBF_LAUNCH(SP, S16_, AP_, LDS_)                                                                                                   \
+  do {                                                                                                                                    \
+    if (elu) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<SP, S16_, AP_, true>), dim3(nwg), dim3(512), LDS_, s, a);            \
+    else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<SP, S16_, AP_, false>), dim3(nwg), dim3(512), LDS_, s, a);               \
+  } while (0)
   if (d->precision == LVAE_PREC_BF16) {
     if (with_ap) {
-      if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
-      else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, false, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
-    } else if (a.in_bf16 && a.dx_bf16) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, true>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
-    else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<1, false>), dim3(nwg), dim3(512), gbb_lds(1), s, a);
+      if (a.in_bf16 && a.dx_bf16) GBF_LAUNCH(1, true, true, gbb_lds(1));
+      else GBF_LAUNCH(1, false, true, gbb_lds(1));
+    } else if (a.in_bf16 && a.dx_bf16) GBF_LAUNCH(1, true, false, gbb_lds(1));
+    else GBF_LAUNCH(1, false, false, gbb_lds(1));
   } else if (!f32_mfma) {
     static std::atomic<bool> attr3_set{false};
     if (!attr3_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_gate_bwd_fused_bf16_kernel<3, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
+      hipError_t e = hipSuccess;
+      const void* ks[4] = {(const void*)conv1x1_gate_bwd_fused_bf16_kernel<3, false, false, false>, (const void*)conv1x1_gate_bwd_fused_bf16_kernel<3, false, false, true>,
+                           (const void*)conv1x1_gate_bwd_fused_bf16_kernel<3, false, true, false>, (const void*)conv1x1_gate_bwd_fused_bf16_kernel<3, false, true, true>};
+      for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)gbb_lds(3));
       if (e != hipSuccess) {
         set_error("conv1x1_gate_bwd_fused: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return (int)e;
       }
       attr3_set = true;
     }
-    if (with_ap) hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false, true>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
-    else hipLaunchKernelGGL((conv1x1_gate_bwd_fused_bf16_kernel<3, false>), dim3(nwg), dim3(512), gbb_lds(3), s, a);
+    if (with_ap) GBF_LAUNCH(3, false, true, gbb_lds(3));
+    else GBF_LAUNCH(3, false, false, gbb_lds(3));
+#undef GBF_LAUNCH
   } else {
     hipLaunchKernelGGL(conv1x1_gate_bwd_fused_kernel, dim3(nwg), dim3(512), lds, s, a);
   }
