@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gate_fwd_kernel(GateFwdArgs a)
         acc0[r] += bias_a;
         acc1[r] += bias_b;
       }
+      const f32x16 ga = act_fwd16(acc0, a.act);   // (one uniform branch, not sixteen switch chains)
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
         if (pass < 2 && a.y == nullptr) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = pass == 0 ? acc0[r] : (pass == 1 ? acc1[r] : act_fwd(acc0[r], a.act) * sigmoidf_(acc1[r]));
+          const float v = pass == 0 ? acc0[r] : (pass == 1 ? acc1[r] : ga[r] * sigmoidf_(acc1[r]));
           os[(wrow + (r & 3) + 8 * (r >> 2)) * GF_LDO + li] = v;
         }
         __builtin_amdgcn_wave_barrier();

@@ -334,11 +334,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
           if (bwd) {
             if (d.stats_out) {
               const f32x4 xv[2] = {sx0[q], sx1[q]};
+const f32x4 ag[2] = {act_grad4(xv[0] * piv[0] + bsh[0], d.stats_act), act_grad4(xv[1] * piv[1] + bsh[1], d.stats_act)};
 #pragma unroll
               for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  const float gj = v[h][j] * act_grad(xv[h][j] * piv[h][j] + bsh[h][j], d.stats_act);
+                  const float gj = v[h][j] * ag[h][j];
                   st1[h][j] += gj;
                   st2[h][j] += gj * (xv[h][j] - bmu[h][j]) * brs[h][j];
                 }
@@ -430,9 +431,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(BfArgs a) {
         if (d.stats_mode == LVAE_STATS_BN_BWD) {
           if (d.stats_out) {
             const f32x4 xv = sxr[q];
+            const f32x4 ag = act_grad4(xv * piv + bsh, d.stats_act);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+              const float gj = v[j] * ag[j];
               st1[j] += gj;
               st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
             }

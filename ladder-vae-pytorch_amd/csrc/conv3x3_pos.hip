@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256) void conv3x3_pos_kernel(PosArgs a) {
         const f32x4 bmu = *reinterpret_cast<const f32x4*>(d.stats_pivot + 2 * d.Cout + col);
         const f32x4 brs = *reinterpret_cast<const f32x4*>(d.stats_pivot + 3 * d.Cout + col);
         const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + o);
+        const f32x4 ag = act_grad4(xv * piv + bsh, d.stats_act);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+          const float gj = v[j] * ag[j];
           st1[j] = gj;
           st2[j] = gj * (xv[j] - bmu[j]) * brs[j];
         }

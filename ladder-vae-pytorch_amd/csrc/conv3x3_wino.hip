@@ -575,9 +575,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void conv3x3_wino_kernel(Wino
           if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(d.stats_x + (size_t)((n0 * d.H + oh0) * d.W + p) * d.Cout + col);
+              const f32x4 ag = act_grad4(xv * piv + bsh, d.stats_act);
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+                const float gj = v[j] * ag[j];
                 st1[j] += gj;
                 st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
               }
@@ -962,9 +963,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
           } else if (d.stats_mode == LVAE_STATS_BN_BWD) {
             if (d.stats_out) {
               const f32x4 xv = sxr[q];
+              const f32x4 ag = act_grad4(xv * piv + bsh, d.stats_act);
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float gj = v[j] * act_grad(xv[j] * piv[j] + bsh[j], d.stats_act);
+                const float gj = v[j] * ag[j];
                 st1[j] += gj;
                 st2[j] += gj * (xv[j] - bmu[j]) * brs[j];
               }

@@ -132,6 +132,19 @@ __device__ __forceinline__ f32x4 act_fwd4(f32x4 v, int act) {
   return v;
 }
 
+// one accumulator tile (16 values per lane) through the activation, again with one wave-uniform branch for the common cases
+__device__ __forceinline__ f32x16 act_fwd16(f32x16 v, int act) {
+  if (act == LVAE_ACT_NONE) return v;
+  if (act == LVAE_ACT_ELU) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = v[j] > 0.f ? v[j] : __expf(v[j]) - 1.f;
+    return v;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = act_fwd(v[j], act);
+  return v;
+}
+
 // derivative w.r.t. the pre-activation x
 __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
@@ -141,6 +154,20 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     case LVAE_ACT_SELU: return kSeluScale * (x > 0.f ? 1.f : kSeluAlpha * __expf(x));
     default: return 1.f;
   }
+}
+
+// 4-wide derivative with ONE wave-uniform branch for the common case: with a run-time id every scalar act_grad() call is a chain of scalar
+// compares and taken branches in the emitted code (the statistics epilogues of the dgrad kernels call it per element)
+__device__ __forceinline__ f32x4 act_grad4(f32x4 u, int act) {
+  f32x4 r;
+  if (act == LVAE_ACT_ELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = u[j] > 0.f ? 1.f : __expf(u[j]);
+    return r;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = act_grad(u[j], act);
+  return r;
 }
 
 // derivative expressed from the activation OUTPUT y
