@@ -39,11 +39,11 @@ F_ALG_PER_IMAGE = 10.563e9     # FLOP, fwd + dgrad + wgrad of every convolution 
 B_ALG_PER_IMAGE = 115.93e6     # bytes, fp32 activations in/out of every convolution, fwd + dgrad + wgrad
 B_ALG_PER_IMAGE_BF16 = 57.96e6  # bytes, the same tensors stored in bf16 (BASELINE.md §4 counts 2 B per element)
 PEAK_MFMA_BF16 = 2500.0        # TFLOP/s dense, MI355X_MICROARCH.md
-# committed rocprofv3 summaries of this command (newest round first; tools/r04_final.sh writes them)
-ROCPROF_SUMMARIES = ('profiles/r04_kernel_by_grid.txt', 'profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
-PMC_SUMMARIES = ('profiles/r04_pmc/hbm_traffic.json', 'profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
-PMC_SUMMARIES_BF16 = ('profiles/r04_pmc/hbm_traffic_bf16.json', 'profiles/r03_pmc/hbm_traffic_bf16.json')
-ROCPROF_SUMMARIES_BF16 = ('profiles/r04_bf16_kernel_by_grid.txt', 'profiles/r03_bf16_kernel_by_grid.txt', 'profiles/r02_bf16_kernel_by_grid.txt')
+# committed rocprofv3 summaries of this command (newest round first; tools/r05_final.sh writes them)
+ROCPROF_SUMMARIES = ('profiles/r05_kernel_by_grid.txt', 'profiles/r04_kernel_by_grid.txt', 'profiles/r03_kernel_by_grid.txt', 'profiles/r02_kernel_by_grid.txt')
+PMC_SUMMARIES = ('profiles/r05_pmc/hbm_traffic.json', 'profiles/r04_pmc/hbm_traffic.json', 'profiles/r03_pmc/hbm_traffic.json', 'profiles/r02_pmc/hbm_traffic.json', 'profiles/r01_pmc2/hbm_traffic.json')
+PMC_SUMMARIES_BF16 = ('profiles/r05_pmc/hbm_traffic_bf16.json', 'profiles/r04_pmc/hbm_traffic_bf16.json', 'profiles/r03_pmc/hbm_traffic_bf16.json')
+ROCPROF_SUMMARIES_BF16 = ('profiles/r05_bf16_kernel_by_grid.txt', 'profiles/r04_bf16_kernel_by_grid.txt', 'profiles/r03_bf16_kernel_by_grid.txt', 'profiles/r02_bf16_kernel_by_grid.txt')
 
 
 def first_existing(paths):
