@@ -150,6 +150,12 @@ typedef struct lvae_conv_desc {
  * the direct sum) when the scratch is supplied; without it the direct halo-tile kernel runs. */
 size_t lvae_conv2d_workspace(const lvae_conv_desc* d);
 int lvae_conv2d_f32(const lvae_conv_desc* d, void* stream);
+/* dgrad of a 1x1 / stride-1 convolution whose INPUT was a channel concat (x, x2) — MergeLayer / SkipConnectionMerger,
+ * models/lvae_layers.py:347-359 — in ONE launch (round 5): `d` describes the dgrad over all C1 + C2 input channels exactly as for lvae_conv2d_f32
+ * (d->x = dy, d->Cout = C1 + C2, transposed weight strides); columns [0, split) are written to d->y [N,H,W,split], columns [split, Cout) to
+ * dx2 [N,H,W,Cout - split]. At most 128 reduction and 128 output channels, multiples of 4; otherwise LVAE_EINVAL (use two launches with
+ * a weight offset, as lvae_conv2d_f32 allows). */
+int lvae_conv1x1_dgrad_cat_f32(const lvae_conv_desc* d, float* dx2, int32_t split, void* stream);
 /* Which kernel family lvae_conv2d_f32 runs for `d` as given (workspace and form included): diagnostics for the parity tests and for
  * bench.py's roofline record (which matrix unit issues the FLOPs). */
 enum {

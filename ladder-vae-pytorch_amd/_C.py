@@ -81,6 +81,7 @@ SIGNATURES = {
     'lvae_conv2d_workspace': (_Z, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_f32': (C.c_int, [C.POINTER(ConvDesc), _P]),
     'lvae_conv2d_bf16': (C.c_int, [C.POINTER(ConvDesc), _P]),
+    'lvae_conv1x1_dgrad_cat_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _I, _P]),
     'lvae_conv2d_stats_rows': (_I, [C.POINTER(ConvDesc)]),
     'lvae_conv2d_variant': (_I, [C.POINTER(ConvDesc)]),
     'lvae_resblock_bf16_storage': (_I, [C.POINTER(ConvDesc)]),

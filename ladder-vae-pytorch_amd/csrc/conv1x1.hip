@@ -27,6 +27,11 @@ struct PwArgs {
   const float* gb_ab;
   float* gb_dab;
   int gb_act;
+  // two output tensors (plain epilogue only): columns [0, split) go to d.y with row pitch `split`, columns [split, N) to y2 with row pitch
+  // N - split — the dgrad of a convolution whose input was a channel concat of two tensors (MergeLayer, models/lvae_layers.py:347-359) in
+  // ONE launch instead of one per half (round 5). y2 == nullptr: one tensor, row pitch N.
+  float* y2;
+  int split;
 };
 
 template <int BM, int KT, int NT, bool B_KCONTIG>
@@ -258,7 +263,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(PwArgs a) {
       if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + c);
       if (d.out_scale) v = v * *reinterpret_cast<const f32x4*>(d.out_scale + (size_t)(m / a.ohw) * N + c);
       v = act_fwd4(v, d.out_act);
-      store_wt4(d.y + (size_t)m * N + c, v);
+      if (a.y2 == nullptr) store_wt4(d.y + (size_t)m * N + c, v);
+      else if (c < a.split) store_wt4(d.y + (size_t)m * a.split + c, v);
+      else store_wt4(a.y2 + (size_t)m * (N - a.split) + (c - a.split), v);
     }
   }
 }
@@ -294,8 +301,8 @@ static int pick_bm(const PwArgs& a, hipStream_t s) {
 }
 
 // -1000: not eligible (the caller uses the generic kernel)
-int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
-                   const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s) {
+static int conv1x1_try_all(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
+                           const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s, float* y2, int split) {
   const int K = d->C1 + d->C2, N = d->Cout;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->OH != d->H || d->OW != d->W) return -1000;
   if (K > 128 || N > 128 || d->C1 % 4 || d->C2 % 4 || N % 4 || (gate_out && N % 8)) return -1000;
@@ -319,6 +326,9 @@ int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_o
   a.gb_ab = gb_ab;
   a.gb_dab = gb_dab;
   a.gb_act = gb_act;
+  a.y2 = y2;
+  a.split = split;
+  if (y2 != nullptr && (gate_out != nullptr || d->stats_out != nullptr || split <= 0 || split >= N || split % 4 != 0 || !al16p(y2))) return -1000;
   const bool k64 = K <= 64, n64 = N <= 64;
   if (nc) {
     if (k64) return n64 ? pick_bm<64, 64, false>(a, s) : pick_bm<64, 128, false>(a, s);
@@ -328,8 +338,31 @@ int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_o
   return n64 ? pick_bm<128, 64, true>(a, s) : pick_bm<128, 128, true>(a, s);
 }
 
+int conv1x1_try_ex(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, const float* gb_dout,
+                   const float* gb_ab, float* gb_dab, int gb_act, hipStream_t s) {
+  return conv1x1_try_all(d, gate_res, gate_out, gate_act, gb_dout, gb_ab, gb_dab, gb_act, s, nullptr, 0);
+}
+
 int conv1x1_try(const lvae_conv_desc* d, const float* gate_res, float* gate_out, int gate_act, hipStream_t s) {
-  return conv1x1_try_ex(d, gate_res, gate_out, gate_act, nullptr, nullptr, nullptr, 0, s);
+  return conv1x1_try_all(d, gate_res, gate_out, gate_act, nullptr, nullptr, nullptr, 0, s, nullptr, 0);
 }
 
 }  // namespace lvae
+
+namespace lvae {
+int conv_desc_check(const lvae_conv_desc* d, const char* who);
+}
+using namespace lvae;
+
+extern "C" int lvae_conv1x1_dgrad_cat_f32(const lvae_conv_desc* d, float* dx2, int32_t split, void* stream) {
+  int rc = conv_desc_check(d, "lvae_conv1x1_dgrad_cat_f32");
+  if (rc) return rc;
+  LVAE_REQUIRE(d->y != nullptr && dx2 != nullptr && split > 0 && split < d->Cout && split % 4 == 0 && d->stats_out == nullptr && d->x2 == nullptr,
+               LVAE_EINVAL, "lvae_conv1x1_dgrad_cat_f32: needs y, dx2, 0 < split < Cout (a multiple of 4), no statistics epilogue, one input tensor");
+  LVAE_REQUIRE(d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32, LVAE_EINVAL, "lvae_conv1x1_dgrad_cat_f32: fp32 tensors only");
+  rc = conv1x1_try_all(d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, dx2, split);
+  LVAE_REQUIRE(rc != -1000, LVAE_EINVAL,
+               "lvae_conv1x1_dgrad_cat_f32: shape not supported (1x1, stride 1, at most 128 reduction and 128 output channels, multiples of 4, "
+               "16-byte aligned tensors, unit weight stride along one axis): use two lvae_conv2d_f32 launches");
+  return rc;
+}

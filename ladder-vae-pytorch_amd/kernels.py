@@ -709,6 +709,25 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=Non
     return dx, parts
 
 
+def conv1x1_dgrad_cat(dy, weight, g, C1):
+    """Both halves of the input gradient of a 1x1 / stride-1 convolution whose input was the channel concat (x [.., C1], x2 [.., Cin - C1]),
+    in one launch: returns (dx, dx2), or None when the shape is not the single-shot 1x1 kernel's (the caller launches one dgrad per half)."""
+    if not (g.KH == 1 and g.KW == 1 and g.stride == 1 and g.pad == 0 and not g.transposed and dy.dtype == torch.float32):
+        return None
+    K_, N_ = g.Cout, g.Cin
+    kc = g.s_co == 1 and g.s_ci % 4 == 0
+    nc = g.s_ci == 1 and g.s_co % 4 == 0
+    if K_ > 128 or N_ > 128 or K_ % 4 or N_ % 4 or C1 % 4 or not (0 < C1 < N_) or not (kc or nc):
+        return None
+    _chk_nhwc(dy, 'dy')
+    N, H, W, _ = dy.shape
+    dx = torch.empty((N, H, W, C1), dtype=torch.float32, device=dy.device)
+    dx2 = torch.empty((N, H, W, N_ - C1), dtype=torch.float32, device=dy.device)
+    d = _desc(g, weight, dy, None, N, H, W, H, W, N_, g.s_co, g.s_ci, GATHER_TRANSPOSED, y=dx)
+    call('lvae_conv1x1_dgrad_cat_f32', C.byref(d), ptr(dx2), C1, stream_ptr())
+    return dx, dx2
+
+
 def conv2d_wgrad(x, dy, weight, g, dweight, dbias=None, x2=None, in_scale=None, in_shift=None, in_act=None):
     """dweight += d/dw, dbias += d/db for the convolution of `conv2d` with the same fused input transform.
     dweight must have the same strides as weight (a view of the gradient arena)."""

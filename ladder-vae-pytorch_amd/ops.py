@@ -110,6 +110,9 @@ def wgrad(x, dy, w, g, dw, db, **kw):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+_DGRAD_CAT = os.environ.get('LVAE_DGRAD_CAT', '1') != '0'   # A/B switch, profiling only
+
+
 class ConvFn(Function):
     """y = out_act(conv(cat(x, x2)) + bias); call sites: stem, pre_conv (strided / transposed), merge 1x1,
     stochastic convs, likelihood head. `mod` is the parameter holder (lib.nn.Conv2dParams)."""
@@ -140,10 +143,14 @@ class ConvFn(Function):
                 dx = K.conv2d_dgrad(dy, w, g, hw)
         else:
             C1 = x.shape[3]
-            if ctx.needs_input_grad[0]:
-                dx = K.conv2d_dgrad(dy, w, g, hw, ci_range=(0, C1))
-            if ctx.needs_input_grad[1]:
-                dx2 = K.conv2d_dgrad(dy, w, g, hw, ci_range=(C1, g.Cin))
+            both = K.conv1x1_dgrad_cat(dy, w, g, C1) if (_DGRAD_CAT and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]) else None
+            if both is not None:
+                dx, dx2 = both   # merge / skip 1x1: both halves of the channel concat from one launch
+            else:
+                if ctx.needs_input_grad[0]:
+                    dx = K.conv2d_dgrad(dy, w, g, hw, ci_range=(0, C1))
+                if ctx.needs_input_grad[1]:
+                    dx2 = K.conv2d_dgrad(dy, w, g, hw, ci_range=(C1, g.Cin))
         return dx, dx2, None, None, None, None
 
 

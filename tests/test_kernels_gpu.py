@@ -284,6 +284,27 @@ def test_conv_fused_prologue_epilogue_and_cat(K):
     assert rel(nchw(dx), xin.grad) < 2e-6
 
 
+
+@pytest.mark.parametrize('case', [(256, 64, 64, 64, 4, 4), (33, 64, 64, 64, 16, 16), (5, 32, 96, 64, 8, 8), (70, 64, 64, 128, 2, 2)])
+def test_conv1x1_dgrad_of_a_channel_concat_in_one_launch(K, case):
+    """lvae_conv1x1_dgrad_cat_f32: both halves of the input gradient of MergeLayer's 1x1 convolution over cat(x, x2) == the two launches with a
+    weight offset (bitwise: same kernel, same reduction order), and == F.conv_transpose2d."""
+    N, C1, C2, Co, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = torch.randn(Co, C1 + C2, 1, 1, generator=g) / math.sqrt(C1 + C2)
+    dy = torch.randn(N, Co, H, W, generator=g)
+    wp = packed_weight(w)
+    geom = K.ConvGeom(wp, 1, 0)
+    both = K.conv1x1_dgrad_cat(nhwc(dy), wp, geom, C1)
+    assert both is not None
+    dx, dx2 = both
+    a = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W), ci_range=(0, C1))
+    b = K.conv2d_dgrad(nhwc(dy), wp, geom, (H, W), ci_range=(C1, C1 + C2))
+    assert torch.equal(dx, a) and torch.equal(dx2, b)
+    ref = F.conv_transpose2d(dy.double(), w.double())
+    assert rel(nchw(dx).double(), ref[:, :C1]) < 3e-6 and rel(nchw(dx2).double(), ref[:, C1:]) < 3e-6
+
+
 @pytest.mark.parametrize('shape', [(8, 64, 16, 16), (3, 8, 5, 7), (4, 3, 6, 6), (64, 64, 32, 32)])
 def test_bn_stats_and_affine_bwd(K, shape):
     g = torch.Generator().manual_seed(5)
