@@ -191,7 +191,8 @@ def _rb_next_ranges(direction, blk):
 # output of the previous residual block of the chain (lib/nn.py hands the producer over with the tensor object, like the BatchNorm
 # partials) and that block's backward starts with a kernel that can form its `dout` itself (the fused gate-backward launches), the apply
 # is not launched: the block returns an unwritten dx and leaves a kernels.PendingApply with the consumer, whose first launch computes dx
-# in its prologue and stores it there. LVAE_DEFER_APPLY=0 (profiling only) keeps the launch.
+# in its prologue and stores it there. This assumes what loss.backward() does: the backward pass continues through the producing block
+# (torch.autograd.grad with respect to a tensor BETWEEN two such blocks would be handed the unwritten dx). LVAE_DEFER_APPLY=0 keeps the launch.
 _DEFER_APPLY = os.environ.get('LVAE_DEFER_APPLY', '1') != '0'
 _DEFER_LARGE = os.environ.get('LVAE_DEFER_APPLY_LARGE', '1') != '0'   # ... also into the persistent gate-backward kernel of the >= 16x16 levels
 
