@@ -60,7 +60,7 @@ def join_wgrad_stream():
             torch.cuda.current_stream().wait_stream(st)
 
 
-def set_wgrad_grouping(max_rows, flush_at=int(os.environ.get('LVAE_WGRAD_FLUSH', '288'))):
+def set_wgrad_grouping(max_rows, flush_at=int(os.environ.get('LVAE_WGRAD_FLUSH', '1024'))):
     """Queue the weight gradients of layers with at most `max_rows` pixels (N*H*W) and issue them `flush_at` at a time (measured
     on the CIFAR-15 step: 12 -> 43.6 ms, 72 -> 42.8, 288 -> 42.4: fuller groups of each kernel variant; the queued (x, dy) pairs
     are at most 4 MB each) through
@@ -94,7 +94,7 @@ def wgrad(x, dy, w, g, dw, db, **kw):
             flush_wgrad_group()  # two gradients of one weight must not share a launch
             q = _side['group_q']
         q.append((x, dy, w, g, dw, db, kw))
-        if len(q) >= _side.get('group_at', 288):
+        if len(q) >= _side.get('group_at', 1024):
             flush_wgrad_group()
         return
     sts = _side['stream']
