@@ -245,6 +245,7 @@ typedef struct lvae_bn_apply {
   float* out;
   int32_t dh_bf16;
   int32_t reserved_;
+  const float* drop;   /* lvae_conv2d_wgrad_apply_f32 only: Dropout2d mask [N][C] multiplied into the result, or NULL */
 } lvae_bn_apply;
 size_t lvae_conv1x1_gate_bwd_wgrad_workspace(const lvae_conv_desc* d);
 int lvae_conv1x1_gate_bwd_wgrad_f32(const lvae_conv_desc* d, const float* dout, const float* ab, const float* y, int32_t act,
@@ -359,6 +360,14 @@ int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, float* dw, f
  * kernel (anything but 3x3 / stride 1 / <= 64 input channels / >= 16384 pixels) run in fp32. */
 int lvae_conv2d_wgrad_bf16(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Weight gradient whose dY operand is the result of a BatchNorm-backward apply that has not run (round 5): dy = BN'(ap->dh; ap->x) * ap->drop
+ * — exactly lvae_affine_act_bwd_parts_f32(parts, dh, x, ..., drop) — is formed while the kernel stages its operand, stored to ap->out
+ * [N,H,W,64] for the dgrad that follows, and used as dY; ap->dgamma / dbeta are accumulated. One launch, its finalize launch and one
+ * tensor pass per BatchNorm less. lvae_conv2d_wgrad_apply_ok(d) != 0: the Winograd-domain fp32 weight gradient of a 64 -> 64 layer with
+ * W = 16 or 32 (the >= 16x16 levels at batch 256). ap->add must be NULL, dh fp32. */
+int32_t lvae_conv2d_wgrad_apply_ok(const lvae_conv_desc* d);
+int lvae_conv2d_wgrad_apply_f32(const lvae_conv_desc* d, const lvae_bn_apply* ap, float* dw, float* db, void* workspace,
+                                size_t workspace_bytes, void* stream);
 /* Which kernel family lvae_conv2d_wgrad_f32 (and the grouped call) runs for `d` (d->x_dtype / y_dtype = the storage types of x / dy):
  * diagnostics for the parity tests and the profiles. */
 enum {

@@ -51,7 +51,7 @@ class BnApply(C.Structure):
     """mirror of struct lvae_bn_apply"""
     _fields_ = [('parts', C.c_void_p), ('rows', C.c_int32), ('act', C.c_int32), ('M', C.c_int64), ('coef', C.c_void_p), ('dh', C.c_void_p),
                 ('x', C.c_void_p), ('add', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('out', C.c_void_p),
-                ('dh_bf16', C.c_int32), ('reserved_', C.c_int32)]
+                ('dh_bf16', C.c_int32), ('reserved_', C.c_int32), ('drop', C.c_void_p)]
 
 
 class RbExt(C.Structure):
@@ -106,6 +106,8 @@ SIGNATURES = {
     'lvae_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_bf16': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_variant': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_conv2d_wgrad_apply_ok': (_I, [C.POINTER(ConvDesc)]),
+    'lvae_conv2d_wgrad_apply_f32': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnApply), _P, _P, _P, _Z, _P]),
     'lvae_conv2d_wgrad_grouped_workspace': (_Z, [C.POINTER(ConvDesc), _I]),
     'lvae_conv2d_wgrad_grouped_f32': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _Z, _P]),
     'lvae_bn_stats_workspace': (_Z, [_L, _I]),

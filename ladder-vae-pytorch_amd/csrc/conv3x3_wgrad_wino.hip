@@ -38,6 +38,23 @@ template <int TPR>  // Winograd tiles per image row (W / 2): 4, 8 or 16; a chunk
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(WgWinoArgs a) {
   kernarg_warmup<sizeof(WgWinoArgs)>();
   const int nwg_ = gridDim.x;
+  constexpr bool AP = false;
+  const lvae_bn_apply ap = lvae_bn_apply{};
+#include "conv3x3_wgrad_wino_body.inc"
+}
+
+// the same kernel with the BatchNorm-backward apply that produces its dY operand in front (see the body's header)
+struct WgWinoApArgs {
+  WgWinoArgs w;
+  lvae_bn_apply ap;
+};
+template <int TPR>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_ap_kernel(WgWinoApArgs g) {
+  kernarg_warmup<sizeof(WgWinoApArgs)>();
+  const WgWinoArgs& a = g.w;
+  const lvae_bn_apply& ap = g.ap;
+  const int nwg_ = gridDim.x;
+  constexpr bool AP = true;
 #include "conv3x3_wgrad_wino_body.inc"
 }
 
@@ -54,6 +71,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_grouped_kernel(WgWinoG
   const WgWinoArgs& a = g.p[blockIdx.y];
   const int nwg_ = a.nranges * a.ncog * 2;
   if ((int)blockIdx.x >= nwg_) return;  // uniform per workgroup, before any barrier
+  constexpr bool AP = false;
+  const lvae_bn_apply ap = lvae_bn_apply{};
 #include "conv3x3_wgrad_wino_body.inc"
 }
 
@@ -224,6 +243,52 @@ int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, flo
   if (d->W == 8) rc = launch_wg_wino<4>(a, s);
   else if (d->W == 16) rc = launch_wg_wino<8>(a, s);
   else rc = launch_wg_wino<16>(a, s);
+  if (rc) return rc;
+  const WinoReduceArgs ra{a.slab_w, a.slab_b, a.nranges, a.ncog, d->Cout, 0, d->w_stap, d->w_sk, d->w_sn, dw, db};
+  hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(128 * a.ncog), dim3(1024), 0, s, ra);
+  LVAE_LAUNCH_CHECK("conv_wgrad_wino_reduce");
+  return 0;
+}
+
+template <int TPR>
+static int launch_wg_wino_ap(const WgWinoApArgs& g, hipStream_t s) {
+  auto kern = conv_wgrad_wino_ap_kernel<TPR>;
+  constexpr int W = 2 * TPR, HW2 = W + 2, TR = 16 / TPR, HP = (2 * TR + 2) * HW2;
+  size_t lds = (size_t)2 * (HP * WG_XS + 64 * WG_DS) * sizeof(float);
+  const size_t lds_r = (size_t)(4 * 4 * 2 * 16 * 64 + 128) * sizeof(float);
+  if (lds < lds_r) lds = lds_r;
+  static std::atomic<bool> attr_set{false};  // idempotent attribute write; the flag itself is race-free
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv_wgrad_wino_ap: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.w.nranges * g.w.ncog * 2), dim3(512), lds, s, g);
+  LVAE_LAUNCH_CHECK("conv_wgrad_wino_ap");
+  return 0;
+}
+
+// 1 when the weight gradient of `d` can take its dY operand from a deferred BatchNorm-backward apply (lvae_conv2d_wgrad_apply_f32)
+bool conv_wgrad_wino_apply_ok(const lvae_conv_desc* d) {
+  WgWinoArgs a;
+  return d != nullptr && d->Cout == 64 && d->W == 16 && d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32 && wg_wino_plan(d, a);
+}
+
+// returns -1000 when not eligible
+int conv_wgrad_wino_apply_try(const lvae_conv_desc* d, const lvae_bn_apply* ap, float* dw, float* db, void* workspace, hipStream_t s) {
+  WgWinoApArgs g;
+  WgWinoArgs& a = g.w;
+  if (!conv_wgrad_wino_apply_ok(d) || !wg_wino_plan(d, a) || !al16g(workspace)) return -1000;
+  if (!al16g(ap->parts) || !al16g(ap->coef) || !al16g(ap->dh) || !al16g(ap->x) || !al16g(ap->out) || !al16g(ap->drop)) return -1000;
+  a.d = *d;
+  a.dy = nullptr;
+  a.slab_w = static_cast<float*>(workspace);
+  a.slab_b = db ? a.slab_w + (size_t)a.nranges * a.ncog * 2 * 16 * 32 * 64 : nullptr;
+  g.ap = *ap;
+  int rc = d->W == 16 ? launch_wg_wino_ap<8>(g, s) : launch_wg_wino_ap<16>(g, s);
   if (rc) return rc;
   const WinoReduceArgs ra{a.slab_w, a.slab_b, a.nranges, a.ncog, d->Cout, 0, d->w_stap, d->w_sk, d->w_sn, dw, db};
   hipLaunchKernelGGL(conv_wgrad_wino_reduce_kernel, dim3(128 * a.ncog), dim3(1024), 0, s, ra);

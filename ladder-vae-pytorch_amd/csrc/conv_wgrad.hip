@@ -399,6 +399,8 @@ int conv_wgrad_tile_kind(const lvae_conv_desc* d);
 int conv_wgrad_tile_grouped(const lvae_conv_desc* const* ds, const float* const* dy, float* const* dw, float* const* db,
                             void* const* workspace, int n, int kind, hipStream_t s);
 int conv_wgrad_wino_try(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace, hipStream_t s);
+bool conv_wgrad_wino_apply_ok(const lvae_conv_desc* d);
+int conv_wgrad_wino_apply_try(const lvae_conv_desc* d, const lvae_bn_apply* ap, float* dw, float* db, void* workspace, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight gradient of the stem convolutions (5x5 stride 2 on the 1- or 3-channel image): the reduction dimension of the
@@ -609,6 +611,27 @@ extern "C" int lvae_conv2d_wgrad_f32(const lvae_conv_desc* d, const float* dy, f
   wgrad_reduce_launch(a.slab_w, a.slab_b, a.ksplit, a.ntaps, a.Cin, d->Cout, d->w_stap, d->w_sk, d->w_sn, dw, db, s);
   LVAE_LAUNCH_CHECK("conv2d_wgrad_reduce");
   return 0;
+}
+
+extern "C" int32_t lvae_conv2d_wgrad_apply_ok(const lvae_conv_desc* d) {
+  return d != nullptr && d->precision == LVAE_PREC_F32 && lvae_conv2d_wgrad_variant(d) == LVAE_WGRAD_VARIANT_WINO && conv_wgrad_wino_apply_ok(d) ? 1 : 0;
+}
+
+extern "C" int lvae_conv2d_wgrad_apply_f32(const lvae_conv_desc* d, const lvae_bn_apply* ap, float* dw, float* db, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  int rc = conv_desc_check(d, "lvae_conv2d_wgrad_apply_f32");
+  if (rc) return rc;
+  LVAE_REQUIRE(lvae_conv2d_wgrad_apply_ok(d), LVAE_EINVAL,
+               "lvae_conv2d_wgrad_apply_f32: shape not supported (the Winograd-domain fp32 weight gradient of a 64 -> 64 layer, W = 16 or 32): "
+               "use lvae_affine_act_bwd_parts_f32 + lvae_conv2d_wgrad_f32");
+  LVAE_REQUIRE(ap && ap->parts && ap->rows > 0 && ap->M == (int64_t)d->N * d->H * d->W && ap->coef && ap->dh && ap->x && ap->out && ap->add == nullptr &&
+                   ap->dh_bf16 == 0 && dw && workspace,
+               LVAE_EINVAL, "lvae_conv2d_wgrad_apply_f32: needs parts / rows, M = N*H*W, the coefficient block, fp32 dh, x and out, no add");
+  LVAE_REQUIRE(workspace_bytes >= lvae_conv2d_wgrad_workspace(d), LVAE_EWORKSPACE, "lvae_conv2d_wgrad_apply_f32: workspace %zu < %zu", workspace_bytes,
+               lvae_conv2d_wgrad_workspace(d));
+  rc = conv_wgrad_wino_apply_try(d, ap, dw, db, workspace, (hipStream_t)stream);
+  LVAE_REQUIRE(rc != -1000, LVAE_EALIGN, "lvae_conv2d_wgrad_apply_f32: buffers must be 16-byte aligned");
+  return rc;
 }
 
 extern "C" int lvae_conv2d_wgrad_bf16(const lvae_conv_desc* d, const float* dy, float* dw, float* db, void* workspace,

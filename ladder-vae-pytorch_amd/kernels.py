@@ -709,6 +709,33 @@ def conv2d_dgrad(dy, weight, g, in_hw, out_scale=None, ci_range=None, bn_bwd=Non
     return dx, parts
 
 
+def conv2d_wgrad_apply_ok(x, weight, g):
+    """True when conv2d_wgrad_apply takes the 3x3 convolution (weight, g) on input x (the Winograd-domain fp32 weight gradient of a
+    64 -> 64 layer at the >= 16x16 levels)."""
+    if precision != PREC_F32 or x.dtype != torch.float32 or x.dim() != 4 or g.transposed or _ddi is not None:
+        return False
+    N, H, W, _ = x.shape
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV)
+    return bool(_C.load().lvae_conv2d_wgrad_apply_ok(C.byref(d)))
+
+
+def conv2d_wgrad_apply(x, weight, g, dweight, dbias, parts, dh, xbn, coef0, act, dgamma, dbeta, drop=None, in_scale=None, in_shift=None, in_act=None):
+    """conv2d_wgrad whose dy operand is the BatchNorm-backward apply that has not run: dy = affine_act_bwd_parts(parts, dh, xbn, ..., drop=drop)
+    is formed inside the weight-gradient kernel, stored and returned (the dgrad that follows reads it). coef0: row 0 of the (4, C) coefficient
+    block of the BatchNorm being differentiated; dgamma / dbeta are accumulated. Only where conv2d_wgrad_apply_ok()."""
+    _chk_nhwc(x, 'x')
+    N, H, W, _ = x.shape
+    if tuple(dweight.stride()) != tuple(weight.stride()):
+        raise _C.LvaeHipError("conv2d_wgrad_apply: gradient strides differ from weight strides")
+    d = _desc(g, weight, x, None, N, H, W, H, W, g.Cout, g.s_ci, g.s_co, GATHER_CONV, None, in_scale, in_shift, in_act)
+    need = _C.load().lvae_conv2d_wgrad_workspace(C.byref(d))
+    ws = workspace(need, x.device)
+    dy = torch.empty((N, H, W, g.Cout), dtype=torch.float32, device=x.device)
+    ap = _C.BnApply(ptr(parts), parts.shape[0], ACT[act], N * H * W, ptr(coef0), ptr(dh), ptr(xbn), None, ptr(dgamma), ptr(dbeta), ptr(dy), 0, 0, ptr(drop))
+    call('lvae_conv2d_wgrad_apply_f32', C.byref(d), C.byref(ap), ptr(dweight), ptr(dbias), ws.data_ptr(), ws.numel(), stream_ptr())
+    return dy
+
+
 def conv1x1_dgrad_cat(dy, weight, g, C1):
     """Both halves of the input gradient of a 1x1 / stride-1 convolution whose input was the channel concat (x [.., C1], x2 [.., Cin - C1]),
     in one launch: returns (dx, dx2), or None when the shape is not the single-shot 1x1 kernel's (the caller launches one dgrad per half)."""

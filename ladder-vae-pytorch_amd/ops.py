@@ -111,6 +111,7 @@ def wgrad(x, dy, w, g, dw, db, **kw):
 
 # ----------------------------------------------------------------------------------------------------------------
 _DGRAD_CAT = os.environ.get('LVAE_DGRAD_CAT', '1') != '0'   # A/B switch, profiling only
+_WGRAD_APPLY = os.environ.get('LVAE_WGRAD_APPLY', '1') != '0'   # A/B switch, profiling only
 
 
 class ConvFn(Function):
@@ -400,15 +401,24 @@ class ResBlockFn(Function):
             dh2, parts2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw, bn_bwd=(y1, sc2, act), out_bf16=s16)
         else:
             dh2 = K.conv2d_dgrad(dy2, w2, blk.conv2.geom(), hw)
-        if parts2 is not None:
+        w1 = blk.conv1.weight
+        wg1_done = False
+        if (parts2 is not None and _WGRAD_APPLY and not s16 and _side['stream'] is None and w1.requires_grad and dh2.dtype == torch.float32 and
+                K.conv2d_wgrad_apply_ok(x, w1, blk.conv1.geom())):
+            # >= 16x16 levels (fp32): the BatchNorm-2 apply runs inside conv1's weight-gradient kernel, which needs its result as an operand
+            # anyway (and stores it for the dgrad below): one launch, its finalize and one tensor pass less
+            dy1 = K.conv2d_wgrad_apply(x, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), parts2, dh2, y1, sc2, act,
+                                       grad_buf(bn2.weight), grad_buf(bn2.bias), drop=m1, in_scale=sc1, in_shift=sh1, in_act=act)
+            wg1_done = True
+        elif parts2 is not None:
             dy1 = K.affine_act_bwd_parts(parts2, dh2, y1, sc2, sh2, act, mean2, rstd2, grad_buf(bn2.weight), grad_buf(bn2.bias),
                                          drop=m1, out_bf16=s16)
         else:
             dy1 = K.affine_act_bwd(dh2, y1, sc2, sh2, act, train2, mean2, rstd2,
                                    grad_buf(bn2.weight) if train2 else None, grad_buf(bn2.bias) if train2 else None, drop=m1)
         # first half
-        w1 = blk.conv1.weight
-        wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
+        if not wg1_done:
+            wgrad(x, dy1, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), in_scale=sc1, in_shift=sh1, in_act=act)
         bn1 = blk.bn1
         train1 = bn1 is not None and ctx.training
         parts1 = None

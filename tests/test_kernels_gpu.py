@@ -909,6 +909,40 @@ def test_conv_wgrad_whole_image_tiles(K, case, prec):
     assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 3e-6   # the bias gradient sums the unrounded dy
 
 
+@pytest.mark.parametrize('shape', [(256, 16, 16), (70, 16, 16), (130, 16, 16)])
+def test_weight_gradient_that_absorbs_the_batchnorm_apply_in_front_of_it(K, shape):
+    """lvae_conv2d_wgrad_apply_f32 == lvae_affine_act_bwd_parts_f32 followed by lvae_conv2d_wgrad_f32: the stored dy (to 1e-6: the partial rows
+    are summed in another order), dgamma / dbeta, and the weight / bias gradient."""
+    N, H, W = shape
+    C = 64
+    g = torch.Generator().manual_seed(N + 7 * H)
+    rn = lambda *s_: torch.randn(*s_, generator=g).cuda()
+    x, dh, xbn = rn(N, H, W, C), rn(N, H, W, C), rn(N, H, W, C)
+    w = packed_weight(torch.randn(C, C, 3, 3, generator=g) / 24)
+    geom = K.ConvGeom(w, 1, 1)
+    assert K.conv2d_wgrad_apply_ok(x, w, geom)
+    coef_in = K.bn_stats(x, None, None, None, None)
+    coef = K.bn_stats(xbn, torch.rand(C, generator=g).cuda() + 0.5, rn(C) * 0.1, None, None)
+    u = xbn * coef[0] + coef[1]
+    gg = dh * torch.where(u > 0, torch.ones_like(u), torch.exp(u))
+    xh = (xbn - coef[2]) * coef[3]
+    rows = 256
+    parts = torch.stack([torch.stack([a.sum(0), b.sum(0)]) for a, b in zip(gg.reshape(-1, C).tensor_split(rows), (gg * xh).reshape(-1, C).tensor_split(rows))]).contiguous()
+    drop = ((torch.rand(N, C, generator=g) < 0.8).float() / 0.8).cuda()
+    dg_a, db_a = torch.full((C,), 0.5, device='cuda'), torch.full((C,), -1.0, device='cuda')
+    dg_b, db_b = dg_a.clone(), db_a.clone()
+    dy_ref = K.affine_act_bwd_parts(parts, dh, xbn, coef[0], coef[1], 'elu', coef[2], coef[3], dg_a, db_a, drop=drop)
+    dw_a, dbias_a = torch.zeros_like(w), torch.zeros(C, device='cuda')
+    K.conv2d_wgrad(x, dy_ref, w, geom, dw_a, dbias_a, in_scale=coef_in[0], in_shift=coef_in[1], in_act='elu')
+    dw_b, dbias_b = torch.zeros_like(w), torch.zeros(C, device='cuda')
+    dy = K.conv2d_wgrad_apply(x, w, geom, dw_b, dbias_b, parts, dh, xbn, coef[0], 'elu', dg_b, db_b, drop=drop, in_scale=coef_in[0], in_shift=coef_in[1], in_act='elu')
+    torch.cuda.synchronize()
+    assert rel(dy.cpu(), dy_ref.cpu()) < 1e-6
+    torch.testing.assert_close(dg_b, dg_a, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db_b, db_a, rtol=1e-5, atol=1e-4)
+    assert rel(dw_b.cpu(), dw_a.cpu()) < 2e-6 and rel(dbias_b.cpu(), dbias_a.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize('nmix', [1, 5, 10, 16, 20])
 def test_dmol_any_component_count_matches_oracle(K, nmix):
     """DiscretizedLogisticMixLikelihood(n_components) of lib/likelihoods.py:183-202 takes any count (the reference only ever builds 10):
