@@ -274,7 +274,7 @@ static int launch_wg_wino_ap(const WgWinoApArgs& g, hipStream_t s) {
 // 1 when the weight gradient of `d` can take its dY operand from a deferred BatchNorm-backward apply (lvae_conv2d_wgrad_apply_f32)
 bool conv_wgrad_wino_apply_ok(const lvae_conv_desc* d) {
   WgWinoArgs a;
-  return d != nullptr && d->Cout == 64 && d->W == 16 && d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32 && wg_wino_plan(d, a);
+  return d != nullptr && d->Cout == 64 && (d->W == 16 || d->W == 32) && d->x_dtype == LVAE_DT_F32 && d->y_dtype == LVAE_DT_F32 && wg_wino_plan(d, a);
 }
 
 // returns -1000 when not eligible

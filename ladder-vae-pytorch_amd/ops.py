@@ -112,6 +112,7 @@ def wgrad(x, dy, w, g, dw, db, **kw):
 # ----------------------------------------------------------------------------------------------------------------
 _DGRAD_CAT = os.environ.get('LVAE_DGRAD_CAT', '1') != '0'   # A/B switch, profiling only
 _WGRAD_APPLY = os.environ.get('LVAE_WGRAD_APPLY', '1') != '0'   # A/B switch, profiling only
+_WGRAD_APPLY_MAXW = int(os.environ.get('LVAE_WGRAD_APPLY_MAXW', '16'))   # 32x32 measured +0.09 ms (profiles/r05_wgrad_apply_ab.txt)
 
 
 class ConvFn(Function):
@@ -404,7 +405,7 @@ class ResBlockFn(Function):
         w1 = blk.conv1.weight
         wg1_done = False
         if (parts2 is not None and _WGRAD_APPLY and not s16 and _side['stream'] is None and w1.requires_grad and dh2.dtype == torch.float32 and
-                K.conv2d_wgrad_apply_ok(x, w1, blk.conv1.geom())):
+                x.shape[2] <= _WGRAD_APPLY_MAXW and K.conv2d_wgrad_apply_ok(x, w1, blk.conv1.geom())):
             # >= 16x16 levels (fp32): the BatchNorm-2 apply runs inside conv1's weight-gradient kernel, which needs its result as an operand
             # anyway (and stores it for the dgrad below): one launch, its finalize and one tensor pass less
             dy1 = K.conv2d_wgrad_apply(x, w1, blk.conv1.geom(), grad_buf(w1), grad_buf(blk.conv1.bias), parts2, dh2, y1, sc2, act,

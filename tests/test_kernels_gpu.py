@@ -909,7 +909,7 @@ def test_conv_wgrad_whole_image_tiles(K, case, prec):
     assert rel(db.cpu() - db0, dy.double().sum((0, 2, 3)).float()) < 3e-6   # the bias gradient sums the unrounded dy
 
 
-@pytest.mark.parametrize('shape', [(256, 16, 16), (70, 16, 16), (130, 16, 16)])
+@pytest.mark.parametrize('shape', [(256, 16, 16), (70, 16, 16), (130, 16, 16), (64, 32, 32), (19, 32, 32)])
 def test_weight_gradient_that_absorbs_the_batchnorm_apply_in_front_of_it(K, shape):
     """lvae_conv2d_wgrad_apply_f32 == lvae_affine_act_bwd_parts_f32 followed by lvae_conv2d_wgrad_f32: the stored dy (to 1e-6: the partial rows
     are summed in another order), dgamma / dbeta, and the weight / bias gradient."""
