@@ -390,7 +390,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' to rehearse N ranks on one GPU)")
     ap.add_argument('--async-wgrad', action='store_true',
                     help='weight-gradient kernels on side streams (measured slower than one stream since the Winograd kernels: 57.0 vs 55.1 ms)')
-    ap.add_argument('--wgrad-group-rows', type=int, default=16384, help='weight gradients of layers with at most this many pixels (N*H*W) are launched in groups (0 = off)')
+    ap.add_argument('--wgrad-group-rows', type=int, default=int(os.environ.get('LVAE_WGRAD_GROUP_ROWS', '16384')), help='weight gradients of layers with at most this many pixels (N*H*W) are launched in groups (0 = off)')
     ap.add_argument('--wgrad-streams', type=int, default=1, help='side streams the weight-gradient kernels are spread over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
