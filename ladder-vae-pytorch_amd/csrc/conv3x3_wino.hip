@@ -719,7 +719,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < SLOTS; ++u) {
-        f32x4 w = act_fwd4(hreg[u] * sc + sh, d.in_act);
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = hreg[u][e] * sc[e] + sh[e];
+        w = act_fwd4(w, d.in_act);
         const bool live = (hlive >> u) & 1u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = live ? w[e] : 0.f;
@@ -798,8 +801,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino2_kernel(WinoArgs a) {
     auto make_af = [&](const f32x4 (&tl)[2][3], const f32x4 (&th)[2][3], int jj, int m, bf16x8 (&af)[3]) {
       f32x4 vl, vh;
       if (jj == 0) {
-        vl = tl[m][0] - tl[m][1];
-        vh = th[m][0] - th[m][1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // element by element: a packed f32 instruction beside MFMAs costs more than its two halves
+          vl[e] = tl[m][0][e] - tl[m][1][e];
+          vh[e] = th[m][0][e] - th[m][1][e];
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
