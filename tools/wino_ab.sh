@@ -13,4 +13,4 @@ for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; ( /opt/rocm/bin/hipcc $FLAGS $f -
 wait
 cd $GRAFT_REPO_ROOT
 for H in ${HS:-16 32}; do for v in "${VS[@]}"; do n=${v%%=*}; echo -n "$n: "; LVAE_DISABLE_WINO2=$(case $n in old*) echo 1;; *) echo 0;; esac) python tools/wino_phase.py $H $DBG/lib_$n.so 2>&1 | grep debug || true; done; done
-for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; case "$f" in *LVAE_WINO_DBG=64*) for H in ${HS:-16}; do LVAE_DISABLE_WINO2=$(case $n in old*) echo 1;; *) echo 0;; esac) python tools/wino_stamps.py $H $DBG/lib_$n.so 2>&1 | grep -v Warn; done;; esac; done
+for v in "${VS[@]}"; do n=${v%%=*}; f=${v#*=}; case "$f" in *LVAE_WINO_DBG=64*) for H in ${HS:-16}; do LVAE_STAMPS_4WAVES=$(case $n in q*) echo 1;; *) echo 0;; esac) LVAE_DISABLE_WINO2=$(case $n in old*) echo 1;; *) echo 0;; esac) python tools/wino_stamps.py $H $DBG/lib_$n.so 2>&1 | grep -v Warn; done;; esac; done

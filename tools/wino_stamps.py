@@ -32,8 +32,8 @@ for name, fn in (('plain', lambda: K.conv2d(x, w, g, bias=b)),
         fn()
     torch.cuda.synchronize()
     w2 = os.environ.get('LVAE_DISABLE_WINO2') != '1'
-    nw = (B * H * H // 256) * 8 if w2 else (B * H * H // 128) * 4
-    nw = min(nw, 1024 * (8 if w2 else 4))
+    nw = (B * H * H // 256) * (4 if os.environ.get('LVAE_STAMPS_4WAVES') == '1' else 8) if w2 else (B * H * H // 128) * 4
+    nw = min(nw, 1024 * ((4 if os.environ.get('LVAE_STAMPS_4WAVES') == '1' else 8) if w2 else 4))
     buf = np.zeros(nw * 8, dtype=np.uint64)
     assert lib.lvae_debug_wino_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)) == 0
     st = buf.reshape(nw, 8)[:, :(8 if w2 else 6)].astype(np.int64)
