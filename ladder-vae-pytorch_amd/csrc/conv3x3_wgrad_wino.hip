@@ -105,20 +105,23 @@ __device__ __forceinline__ void wino_reduce_body(const WinoReduceArgs& a, int bx
   const int q = HALF ? (t & 7) : (t & 15), p = HALF ? ((t >> 3) & 15) : ((t >> 4) & 15), rs = HALF ? (t >> 7) : (t >> 8);
   const float* src = a.slab_w + ((((size_t)(ci >> 5) * ncog + cog) * 32 + (ci & 31)) * 16 + p) * 64 + half * 32 + q * 4;
   const size_t rstride = (size_t)2 * ncog * 32 * 16 * 64;
+  // slab rows p = 4 i + b, b < 3: the producer has applied the column half of G^T dU G (row 4 i + 3 is never written)
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (HALF) {
+  if ((p & 3) != 3) {
+    if (HALF) {
 #pragma unroll 8
-    for (int r = rs; r < nranges; r += 8) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
-    *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
-  } else {
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+      for (int r = rs; r < nranges; r += 8) s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+      *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
+    } else {
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int r = rs; r < nranges; r += 8) {
-      s += *reinterpret_cast<const f32x4*>(src + r * rstride);
-      if (r + 4 < nranges) s1 += *reinterpret_cast<const f32x4*>(src + (r + 4) * rstride);
+      for (int r = rs; r < nranges; r += 8) {
+        s += *reinterpret_cast<const f32x4*>(src + r * rstride);
+        if (r + 4 < nranges) s1 += *reinterpret_cast<const f32x4*>(src + (r + 4) * rstride);
+      }
+      *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
+      *reinterpret_cast<f32x4*>(red + ((rs + 4) * 16 + p) * CW + q * 4) = s1;
     }
-    *reinterpret_cast<f32x4*>(red + (rs * 16 + p) * CW + q * 4) = s;
-    *reinterpret_cast<f32x4*>(red + ((rs + 4) * 16 + p) * CW + q * 4) = s1;
   }
   const bool do_b = a.db != nullptr && ci == 0 && half == 0;
   if (do_b) {
@@ -131,24 +134,19 @@ __device__ __forceinline__ void wino_reduce_body(const WinoReduceArgs& a, int bx
   __syncthreads();
   if (t < 3 * CW && cog * 64 + half * 32 + (t % CW) < a.Cout) {
     const int co = t % CW, ga = t / CW;  // output row a of G^T dU G
-    float u[4][4];
+    float u[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* rp = red + (i * 4 + j) * CW + co;
-        u[i][j] = ((rp[0] + rp[16 * CW]) + (rp[32 * CW] + rp[48 * CW])) + ((rp[64 * CW] + rp[80 * CW]) + (rp[96 * CW] + rp[112 * CW]));
+      for (int b = 0; b < 3; ++b) {
+        const float* rp = red + (i * 4 + b) * CW + co;
+        u[i][b] = ((rp[0] + rp[16 * CW]) + (rp[32 * CW] + rp[48 * CW])) + ((rp[64 * CW] + rp[80 * CW]) + (rp[96 * CW] + rp[112 * CW]));
       }
-    // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
-    float ra[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      ra[j] = ga == 0 ? u[0][j] + 0.5f * (u[1][j] + u[2][j]) : (ga == 1 ? 0.5f * (u[1][j] - u[2][j]) : 0.5f * (u[1][j] + u[2][j]) + u[3][j]);
-    const float g0 = ra[0] + 0.5f * (ra[1] + ra[2]), g1 = 0.5f * (ra[1] - ra[2]), g2 = 0.5f * (ra[1] + ra[2]) + ra[3];
+    // the row half: G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
     float* o = a.dw + (int64_t)ci * a.sk + (int64_t)(cog * 64 + half * 32 + co) * a.sn + (int64_t)(ga * 3) * a.stap;
-    o[0] += g0;
-    o[a.stap] += g1;
-    o[2 * a.stap] += g2;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      o[b * a.stap] += ga == 0 ? u[0][b] + 0.5f * (u[1][b] + u[2][b]) : (ga == 1 ? 0.5f * (u[1][b] - u[2][b]) : 0.5f * (u[1][b] + u[2][b]) + u[3][b]);
   }
   if (do_b && t >= 256 && t < 320 && cog * 64 + t - 256 < a.Cout) {
     const int co = t - 256;
