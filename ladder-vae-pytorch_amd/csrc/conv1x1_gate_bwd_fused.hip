@@ -215,6 +215,11 @@ constexpr size_t gbb_lds(int split) {
 template <int SPLIT, bool S16 = false, bool AP = false, bool ELU = false>
 __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArgs a) {
   kernarg_warmup<sizeof(GbfArgs)>();
+#ifdef LVAE_GBF_DBG  // compile-time phase-skip mask of the profiling builds (tools/gbf_ab.sh); never defined in the product
+  constexpr int dbg = LVAE_GBF_DBG;  // 1: no global loads, 2: no MFMAs, 4: no global stores, 8: no gate derivative arithmetic
+#else
+  constexpr int dbg = 0;
+#endif
   const int gact = ELU ? LVAE_ACT_ELU : a.act, apact = ELU ? LVAE_ACT_ELU : a.ap.act;
   static_assert(SPLIT == 1 || !S16, "bf16 storage exists for the bf16-operand form only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -302,8 +307,38 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
   const int c4 = (t & 15) * 4, r0 = t >> 4;
   const int c8 = (t & 7) * 8, r8 = t >> 3;
   const bool ap_add = AP && a.ap.add != nullptr, ap_dh_bf = AP && a.ap.dh_bf16 != 0;
+  // one of the thread's two rows of a tile (fp32-stored operands): requested as soon as the row before it in the same registers has been
+  // consumed, so that the loads of tile t + 1 fly under the rest of tile t (the loop's barriers wait for LDS only)
+  auto prefetch_row = [&](int tile, int u) {
+    if (dbg & 1) {
+      pg[u] = pa[u] = pb[u] = py[u] = zero4;
+      if (AP) px[u] = pd[u] = zero4;
+      return;
+    }
+    const int m = tile * 64 + r0 + 32 * u;
+    const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
+    if (AP) {
+      pg[u] = load4_dt(a.ap.dh, mc * 64 + c4, ap_dh_bf);
+      px[u] = *reinterpret_cast<const f32x4*>(a.ap.x + mc * 64 + c4);
+      pd[u] = ap_add ? *reinterpret_cast<const f32x4*>(a.ap.add + mc * 64 + c4) : zero4;
+    } else {
+      pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
+    }
+    pa[u] = load4_dt(a.ab, mc * 128 + c4, a.in_bf16 != 0);
+    pb[u] = load4_dt(a.ab, mc * 128 + 64 + c4, a.in_bf16 != 0);
+    py[u] = load4_dt(a.y, mc * 64 + c4, a.in_bf16 != 0);
+  };
   auto prefetch = [&](int tile) {
     const int m0 = tile * 64;
+    if (dbg & 1) {
+      pg[0] = pg[1] = zero4;
+#pragma unroll
+      for (int u = 0; u < IT; ++u) pa[u] = pb[u] = py[u] = zero4;
+#pragma unroll
+      for (int u = 0; u < (AP ? 2 : 1); ++u) px[u] = pd[u] = zero4;
+      qa = qb = qy = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      return;
+    }
     if (S16) {
       const int m = m0 + r8;
       const size_t mc = m < a.M ? (size_t)m : 0;
@@ -324,19 +359,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       return;
     }
 #pragma unroll
-    for (int u = 0; u < IT; ++u) {
-      const int m = m0 + r0 + 32 * u;
-      const size_t mc = m < a.M ? (size_t)m : 0;  // clamped address; the values of rows past the end are zeroed below
-      if (AP) {
-        pg[u] = load4_dt(a.ap.dh, mc * 64 + c4, ap_dh_bf);
-        px[u] = *reinterpret_cast<const f32x4*>(a.ap.x + mc * 64 + c4);
-        pd[u] = ap_add ? *reinterpret_cast<const f32x4*>(a.ap.add + mc * 64 + c4) : zero4;
-      } else
-      pg[u] = *reinterpret_cast<const f32x4*>(a.dout + mc * 64 + c4);
-      pa[u] = load4_dt(a.ab, mc * 128 + c4, a.in_bf16 != 0);
-      pb[u] = load4_dt(a.ab, mc * 128 + 64 + c4, a.in_bf16 != 0);
-      py[u] = load4_dt(a.y, mc * 64 + c4, a.in_bf16 != 0);
-    }
+    for (int u = 0; u < IT; ++u) prefetch_row(tile, u);
   };
 
   f32x16 accw[2];
@@ -394,8 +417,12 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       if (m0 + r < a.M) {
         if (AP) {
           pg[u] = ap_value(pg[u], px[u], pd[u], c4);
-          store_wt4(a.ap.out + (size_t)(m0 + r) * 64 + c4, pg[u]);
+          if (!(dbg & 4)) store_wt4(a.ap.out + (size_t)(m0 + r) * 64 + c4, pg[u]);
         }
+        if (dbg & 8) {
+          lo = pg[u] + pa[u];
+          hi = pg[u] + pb[u];
+        } else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float sg = sigmoidf_(pb[u][j]);
@@ -406,6 +433,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       }
       bs_lo += lo;
       bs_hi += hi;
+      if (tile + (int)gridDim.x < a.ntiles) prefetch_row(tile + gridDim.x, u);
       bf16x4 pl[SPLIT], ph[SPLIT], pyv[SPLIT];
       split4<SPLIT>(lo, pl);
       split4<SPLIT>(hi, ph);
@@ -417,8 +445,8 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
         *reinterpret_cast<bf16x4*>(Ys + q * Y_PLANE + r * GBB_LDY + c4) = pyv[q];
       }
     }
-    __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+    if (S16 && tile + (int)gridDim.x < a.ntiles) prefetch(tile + gridDim.x);
+    lds_barrier();  // the dab / y tiles are published; the prefetched rows stay in flight
 
     if (!wg_role) {
       // ---- dgrad: dx[32 px (wm)][32 ci (wn)] = dab[px][0:128] . W, 8 k-steps of 16
@@ -436,7 +464,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
 #pragma unroll
           for (int q = 0; q < SPLIT; ++q) bw[q] = Wf[((s * 2 + wn) * SPLIT + q) * 64 + lane];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bw[PB[k]], accx, 0, 0, 0);
+          for (int k = 0; k < NP; ++k) { if (dbg & 2) accx[k] += (float)af[PA[k]][0] * (float)bw[PB[k]][1]; else accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bw[PB[k]], accx, 0, 0, 0); }
         } else {
 #pragma unroll
           for (int k = 0; k < NP; ++k) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], breg[s][PB[k]], accx, 0, 0, 0);
@@ -463,11 +491,11 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
             bf[q] = tr_frag(dp, dp + 4 * GBB_LDA);
           }
 #pragma unroll
-          for (int k = 0; k < NP; ++k) accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bf[PB[k]], accw[j], 0, 0, 0);
+          for (int k = 0; k < NP; ++k) { if (dbg & 2) accw[j][k] += (float)af[PA[k]][0] * (float)bf[PB[k]][1]; else accw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[k]], bf[PB[k]], accw[j], 0, 0, 0); }
         }
       }
     }
-    __syncthreads();  // dab / y tiles are dead (the next iteration overwrites them), the dx staging tile is complete
+    lds_barrier();  // dab / y tiles are dead (the next iteration overwrites them), the dx staging tile is complete
     if (S16) {
       const int m = m0 + r8;
       if (m < a.M) {
@@ -486,7 +514,7 @@ __global__ __launch_bounds__(512) void conv1x1_gate_bwd_fused_bf16_kernel(GbfArg
       if (m < a.M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Os + r * GB_LDY + c4);
         if (a.drop) v = v * *reinterpret_cast<const f32x4*>(a.drop + (size_t)(m / a.ohw) * 64 + c4);
-        store4_dt(a.dx, (size_t)m * 64 + c4, v, a.dx_bf16 != 0);
+        if (!(dbg & 4) || v[0] == 12345.678f) store4_dt(a.dx, (size_t)m * 64 + c4, v, a.dx_bf16 != 0);
       }
     }
     // no barrier here: the next write to the staging tile comes after the next iteration's first barrier
