@@ -203,9 +203,9 @@ __device__ __forceinline__ void rb_parts_finish(const float* __restrict__ parts,
 // One launch (7-8.6 us of a dependent chain) per residual block less.
 template <int SPLIT, int MI, int PRO, int EPI, bool ELU, bool AP = false>
 __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
-  static_assert(MI == 1, "64-pixel tiles");
+  static_assert(MI == 1 || MI == 2, "32- or 64-pixel tiles (MI 32-row blocks)");
   static_assert(!AP || PRO == LVAE_RB_PRO_GATE_BWD, "the deferred apply feeds the gate-backward prologue");
-  constexpr int BM = 64, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
+  constexpr int BM = 32 * MI, LDK = RB_LDK, LDO = RB_LDO, NQ = BM / 16;
   constexpr int OS_BYTES = BM * LDO * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   kernarg_warmup<sizeof(RbArgs)>();   // ~600 bytes = ten cache lines, read piecemeal by up to nine dependent s_load batches otherwise
@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   const int in_act = ELU ? LVAE_ACT_ELU : d.in_act, stats_act = ELU ? LVAE_ACT_ELU : d.stats_act;
   const int gate_act = ELU ? LVAE_ACT_ELU : e.act, bwd_act = ELU ? LVAE_ACT_ELU : e.bwd_act, ap_act = ELU ? LVAE_ACT_ELU : e.ap_act;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  // the small 1x1 GEMMs: 64-pixel tiles use a 2 (M) x 2 (N) wave layout; 32-pixel tiles have one row block, so the gate backward's
+  // dgrad GEMM (N = 64) runs on waves 0 / 1 and the gate forward's (N = 128) gives each wave ONE 32-column tile
+  const int wm = MI == 2 ? wave >> 1 : 0, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const bool g1_on = MI == 2 || wave < 2;
   const int bid = blockIdx.x;
   const int n0 = bid * a.NI, HW = a.HW;
   const int nvalid = min(BM, (d.N - n0) * HW);  // pixel rows of this tile that exist
@@ -519,18 +522,22 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    if (g1_on) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      bf16x8 af[SPLIT];
+      for (int s = 0; s < 8; ++s) {
+        bf16x8 af[SPLIT];
 #pragma unroll
-      for (int k = 0; k < SPLIT; ++k) af[k] = *reinterpret_cast<const bf16x8*>(Ds + k * d_plane + (wm * 32 + li) * LDD + 16 * s + 8 * lh);
-      acc1 = mfma_pieces<SPLIT>(af, gq[s], acc1);
+        for (int k = 0; k < SPLIT; ++k) af[k] = *reinterpret_cast<const bf16x8*>(Ds + k * d_plane + (wm * 32 + li) * LDD + 16 * s + 8 * lh);
+        acc1 = mfma_pieces<SPLIT>(af, gq[s], acc1);
+      }
     }
     RB_STAMP(9);
     rb_bar();  // Ds is dead: its head becomes the dy2 staging tile
     float* Os1 = reinterpret_cast<float*>(mainr);
+    if (g1_on) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Os1[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc1[r];
+      for (int r = 0; r < 16; ++r) Os1[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDO + wn * 32 + li] = acc1[r];
+    }
     rb_bar();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -583,17 +590,17 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
 
   // ---- per-lane patch row of its A-fragment pixels (element offset inside a plane; tap (0, 0) = the pixel's upper-left neighbour);
   // this wave's 16-channel block of the reduction dimension
-  int hbase[2];
+  int hbase[MI];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
+  for (int mb = 0; mb < MI; ++mb) {
     const int p = mb * 32 + li;
     const int img = fastdiv(p, a.m_hw), r = p - img * HW;
     const int ty = fastdiv(r, a.m_w), tx = r - ty * d.W;
     hbase[mb] = ((img * a.halo_h + ty) * a.halo_w + tx) * LDK + wave * 16 + 8 * lh;
   }
-  f32x16 acc[2][2];   // [row block][channel half]
+  f32x16 acc[MI][2];   // [row block][channel half]
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MI; ++mb)
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -607,15 +614,15 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   // 9 k-steps per wave (its channel block of every tap), no barrier: B RING taps ahead from L2, A one tap ahead from LDS
   // =====================================================================================================================
   {
-    bf16x8 af[2][2][SPLIT];
-    auto load_a = [&](int tap, bf16x8 (&fa)[2][SPLIT]) {
+    bf16x8 af[2][MI][SPLIT];
+    auto load_a = [&](int tap, bf16x8 (&fa)[MI][SPLIT]) {
       const int kh = tap / 3, kw = tap - kh * 3;
       const int dh = a.flip ? 2 - kh : kh, dw = a.flip ? 2 - kw : kw;
       const int off = (dh * a.halo_w + dw) * LDK;
 #pragma unroll
       for (int p = 0; p < SPLIT; ++p)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) fa[mb][p] = *reinterpret_cast<const bf16x8*>(As + p * a_plane + hbase[mb] + off);
+        for (int mb = 0; mb < MI; ++mb) fa[mb][p] = *reinterpret_cast<const bf16x8*>(As + p * a_plane + hbase[mb] + off);
     };
     load_a(0, af[0]);
 #pragma unroll
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
       const int cur = tap & 1;
       if (tap + 1 < 9) load_a(tap + 1, af[cur ^ 1]);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < MI; ++mb)
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) acc[mb][nh] = mfma_pieces<SPLIT>(af[cur][mb], bq[tap % RING][nh], acc[mb][nh]);
       if (tap + RING < 9) load_b(tap + RING, bq[tap % RING]);
@@ -639,8 +646,10 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int k = 0; k < SPLIT; ++k) {
-        gqa[s][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s * 4 + wn) * SPLIT + k) * 512);
-        gqb[s][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s * 4 + 2 + wn) * SPLIT + k) * 512);
+        // 64-pixel tiles: a-half tile wn and b-half tile 2 + wn; 32-pixel tiles: the ONE column tile `wave` (0, 1: a halves; 2, 3: b halves)
+        gqa[s][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s * 4 + (MI == 2 ? wn : wave)) * SPLIT + k) * 512);
+        if (MI == 2) gqb[s][k] = *reinterpret_cast<const bf16x8*>(gws + ((size_t)(s * 4 + 2 + wn) * SPLIT + k) * 512);
+        else gqb[s][k] = gqa[s][k];
       }
   }
 
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
   float* Os = reinterpret_cast<float*>(mainr);
   constexpr int OSW = BM * LDO;
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MI; ++mb)
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -721,7 +730,7 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
 #pragma unroll
       for (int k = 0; k < SPLIT; ++k) af[k] = *reinterpret_cast<const bf16x8*>(Gs + k * g_plane + (wm * 32 + li) * LDK + 16 * s + 8 * lh);
       acca = mfma_pieces<SPLIT>(af, gqa[s], acca);
-      accb = mfma_pieces<SPLIT>(af, gqb[s], accb);
+      if (MI == 2) accb = mfma_pieces<SPLIT>(af, gqb[s], accb);
     }
     rb_bar();  // the partial tiles and Gs are dead: the region becomes the pre-activation tile [BM][132]
     constexpr int LDG = RB_LDG;
@@ -729,8 +738,12 @@ __global__ __launch_bounds__(256) void rb_conv_kernel(RbArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      Qs[row * LDG + wn * 32 + li] = acca[r];
-      Qs[row * LDG + 64 + wn * 32 + li] = accb[r];
+      if (MI == 2) {
+        Qs[row * LDG + wn * 32 + li] = acca[r];
+        Qs[row * LDG + 64 + wn * 32 + li] = accb[r];
+      } else {
+        Qs[row * LDG + wave * 32 + li] = acca[r];
+      }
     }
     rb_bar();
     stats_out = e.out_stats;
@@ -806,12 +819,18 @@ static int rb_split(const lvae_conv_desc* d) { return d->precision == LVAE_PREC_
 // 32-row blocks per wave: 1 (64-pixel tiles) unless the level has so many pixels that 64-pixel tiles would need more than one round of
 // workgroups (tuning builds can force either)
 static int rb_mi(const lvae_conv_desc* d) {
-  (void)d;
-  return 1;   // 64-pixel tiles (a 128-pixel form existed with the 2 x 2 wave layout of the reduction loop; the k-block layout has none)
+  // 64-pixel tiles (two 32-row blocks), or — round 5 — 32-pixel tiles where 64-pixel tiles would leave at least half of the 256 CUs
+  // without a workgroup (the 4x4 and 2x2 levels at batch 256: 64 / 16 workgroups): a workgroup's reduction loop is MFMA-bound
+  // (216 MFMAs per wave at one wave per SIMD), so half the tile on twice the CUs is half the loop
+  static const int force = (int)tune("LVAE_RB_MI", 0);   // A/B switch (tuning builds only): 1 | 2
+  if (force == 1 || force == 2) return force;
+  const int HW = d->H * d->W;
+  if (HW <= 16 && 32 % HW == 0 && ((int64_t)d->N * HW + 63) / 64 <= 128) return 1;
+  return 2;
 }
 
 static size_t rb_lds_bytes(int split, int mi, int halo_px, int pro, int epi) {
-  const size_t BM = 64 * mi, patch = (size_t)split * halo_px * RB_LDK * 2, os = BM * RB_LDO * 4;
+  const size_t BM = 32 * mi, patch = (size_t)split * halo_px * RB_LDK * 2, os = BM * RB_LDO * 4;
   size_t m = patch > 4 * os ? patch : 4 * os;   // the epilogue's four partial tiles alias the patch
   if (pro == LVAE_RB_PRO_GATE_BWD) {
     const size_t ds = (size_t)split * BM * RB_LDD * 2;
@@ -837,7 +856,7 @@ static bool rb_plan(const lvae_conv_desc* d, RbArgs& a, int& mi) {
   if (d->x_dtype != LVAE_DT_F32 || d->y_dtype != LVAE_DT_F32 || d->stats_x_dtype != LVAE_DT_F32) return false;
   if ((int64_t)d->N * HW * 128 >= ((int64_t)1 << 31)) return false;
   mi = rb_mi(d);
-  const int BM = 64 * mi;
+  const int BM = 32 * mi;
   a.d = *d;
   a.d.in_fold = nullptr;
   a.f = lvae_bn_fold{};
@@ -1042,8 +1061,8 @@ extern "C" int lvae_resblock_conv_f32(const lvae_conv_desc* d, const lvae_rb_ext
   }
   a.Wp = static_cast<const __bf16*>(d->workspace);
   hipStream_t s = (hipStream_t)stream;
-  if (split == 1) return rb_dispatch<1, 1>(a, s);
-  return rb_dispatch<3, 1>(a, s);
+  if (mi == 1) return split == 1 ? rb_dispatch<1, 1>(a, s) : rb_dispatch<3, 1>(a, s);
+  return split == 1 ? rb_dispatch<1, 2>(a, s) : rb_dispatch<3, 2>(a, s);
 }
 
 #ifdef LVAE_RB_DBG
