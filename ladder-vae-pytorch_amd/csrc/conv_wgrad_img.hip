@@ -269,7 +269,11 @@ static int wgi_plan(const lvae_conv_desc* d, WgImgProb& a) {
   // tiles per workgroup: what a gradient costs is launch + first-tile latency per workgroup and 147 KB of slab per workgroup, against
   // ~5 us per further tile; but a gradient should still spread over enough CUs (whole step, one box: 2 -> 33.15 ms, 4 -> 32.69, 8 -> 32.57,
   // 16 -> 32.88; profiles/r05_wgrad_img_ab.txt)
-  static const int tpw = (int)tune("LVAE_WGRAD_IMG_TPW", 8);
+  // Levels with few tiles (2x2 at batch 256: 16) keep at least 8 workgroups per gradient, so that a group of 32 fills the chip.
+  static const int tpw_max = (int)tune("LVAE_WGRAD_IMG_TPW", 8);
+  static const int min_wg = (int)tune("LVAE_WGRAD_IMG_MIN_WG", 8);
+  int tpw = a.ntiles / min_wg;
+  tpw = tpw < 1 ? 1 : (tpw > tpw_max ? tpw_max : tpw);
   int nwg = (a.ntiles + tpw - 1) / tpw;
   if (nwg > 256) nwg = 256;
   if (nwg < 1) nwg = 1;
