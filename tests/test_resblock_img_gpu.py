@@ -76,7 +76,10 @@ def reference(p, act='elu'):
 
 @pytest.mark.parametrize('shape,prec,act', [(s, pr, 'elu') for pr in ('f32', 'bf16') for s in
                                             [(256, 4, 4), (64, 8, 8), (37, 2, 2), (7, 8, 8), (130, 4, 4), (1, 2, 2), (300, 8, 8)]] +
-                         [((40, 4, 4), 'f32', 'selu'), ((9, 8, 8), 'f32', 'leakyrelu'), ((33, 2, 2), 'f32', 'relu')])   # the run-time-activation build
+                         [((40, 4, 4), 'f32', 'selu'), ((9, 8, 8), 'f32', 'leakyrelu'), ((33, 2, 2), 'f32', 'relu')] +   # the run-time-activation build
+                         # tile sizes (round 5): 32-pixel tiles where 64-pixel tiles would fill at most half the CUs (every 4x4 / 2x2 shape above),
+                         # 64-pixel tiles beyond that (600 x 4x4 = 150 tiles), non-square images of 8 pixels (4 per 32-pixel tile)
+                         [((600, 4, 4), 'f32', 'elu'), ((5, 2, 4), 'f32', 'elu'), ((5, 2, 4), 'bf16', 'elu'), ((2100, 2, 2), 'f32', 'elu')])
 def test_fused_block_forward_and_backward(K, shape, prec, act):
     N, H, W = shape
     C = 64
